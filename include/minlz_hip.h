@@ -1,0 +1,111 @@
+/*
+ * minlz_hip.h — C ABI of the MI355X (gfx950) MinLZ block codec.
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no C++/torch
+ * types, re-entrant, no exceptions.  Each entry point names the reference interface it
+ * replaces (file:line into the upstream minio/minlz tree); INTEGRATION.md shows the cgo stub a
+ * maintainer adds on the Go side.
+ *
+ * Two families:
+ *   host-pointer calls   — buffers live in host memory for the duration of the call; the
+ *                          library stages them through pinned buffers it owns (PCIe-bound).
+ *   device-resident calls — src/dst already in HBM; work is queued on the caller's HIP stream
+ *                          and nothing is synchronised (this is what bench.py times).
+ *
+ * Return codes: >= 0 success (or a byte count), < 0 = -MLZ_ERR_*.
+ */
+#ifndef MINLZ_HIP_H
+#define MINLZ_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MLZ_MAX_BLOCK_SIZE (8u << 20) /* minlz.go:84 MaxBlockSize */
+
+/* compression levels, encode.go:25-43 */
+#define MLZ_LEVEL_UNCOMPRESSED 0
+#define MLZ_LEVEL_FASTEST 1
+#define MLZ_LEVEL_BALANCED 2
+
+/* error codes; 1..5 mirror the reference's sentinel errors (decode.go:29-40) */
+#define MLZ_OK 0
+#define MLZ_ERR_CORRUPT 1       /* ErrCorrupt */
+#define MLZ_ERR_TOO_LARGE 2     /* ErrTooLarge */
+#define MLZ_ERR_UNSUPPORTED 3   /* ErrUnsupported: Snappy/S2 fallback blocks (src[0] != 0) */
+#define MLZ_ERR_INVALID_LEVEL 4 /* ErrInvalidLevel */
+#define MLZ_ERR_CRC 5           /* ErrCRC */
+#define MLZ_ERR_DST_TOO_SMALL 6 /* caller's dst cannot hold the result */
+#define MLZ_ERR_HIP 7           /* HIP runtime failure: caller should fall back to its CPU path */
+#define MLZ_ERR_ARG 8           /* bad argument */
+
+typedef struct mlz_ctx mlz_ctx; /* one per (process, device); thread-safe */
+
+/* One block of a batch.  Offsets are relative to the base pointers passed with the batch. */
+typedef struct {
+    uint64_t src_off; /* start of this block's input  */
+    uint64_t src_len; /* its length (encode: <= 8 MiB uncompressed; decode: compressed bytes) */
+    uint64_t dst_off; /* start of this block's output */
+    uint64_t dst_cap; /* room there (encode: >= mlz_max_encoded_len(src_len)) */
+} mlz_block_desc;
+
+/* ---- lifetime ---- */
+/* Creates the context on HIP device `device` (-1 = current).  Replaces nothing in the
+ * reference (its kernels need no state beyond sync.Pool tables, encode_amd64.go:119-189). */
+int mlz_init(int device, mlz_ctx** out);
+void mlz_destroy(mlz_ctx* ctx);
+const char* mlz_last_error(mlz_ctx* ctx); /* text of the last HIP failure on this context */
+/* Library/ABI version and the name of the device the context runs on. */
+int mlz_version(void);
+int mlz_device_name(mlz_ctx* ctx, char* buf, size_t cap);
+
+/* ---- sizes ---- */
+/* MaxEncodedLen (encode.go:234-244): n+2, 1 for n == 0, -1 if n > 8 MiB. */
+int64_t mlz_max_encoded_len(uint64_t n);
+/* DecodedLen / isMinLZ (decode.go:107-156) on a host buffer: >= 0 decoded size, < 0 error. */
+int64_t mlz_decoded_len(const uint8_t* src, size_t n);
+
+/* ---- host-pointer block calls ---- */
+/* minlz.Encode(dst, src, level) (encode.go:74-139): full block `00 uvarint(n) tokens`, or the
+ * stored form `00 00 raw` when incompressible / n < 16.  Returns bytes written. */
+int64_t mlz_encode(mlz_ctx* ctx, int level, const uint8_t* src, size_t n, uint8_t* dst, size_t dst_cap);
+/* minlz.Decode(dst, src) (decode.go:50-78).  Returns decoded bytes. */
+int64_t mlz_decode(mlz_ctx* ctx, const uint8_t* src, size_t n, uint8_t* dst, size_t dst_cap);
+/* WriterCustomEncoder contract (writer.go:1293-1304) == encodeBlock(dst, src) (asm_none.go:51):
+ * token stream only, no header.  > 0 bytes, 0 = incompressible, < 0 = error (decline). */
+int64_t mlz_encode_block(mlz_ctx* ctx, int level, const uint8_t* src, size_t n, uint8_t* dst, size_t dst_cap);
+/* minLZDecode(dst[:n], src) (decode.go:178, decode_amd64.go:28-36): 0 ok, 1 corrupt, < 0 error. */
+int mlz_decode_block(mlz_ctx* ctx, const uint8_t* src, size_t c, uint8_t* dst, size_t n);
+/* Batched host-pointer forms used by the wrapper's Writer/Reader (writer.go:501-560,
+ * reader.go:830-859 fan blocks to goroutines; here one launch covers the batch).
+ * out_len[i] receives the bytes produced for block i or -MLZ_ERR_*. */
+int mlz_encode_batch(mlz_ctx* ctx, int level, int n_blocks, const uint8_t* const* src, const size_t* src_len,
+                     uint8_t* const* dst, const size_t* dst_cap, int64_t* out_len);
+int mlz_decode_batch(mlz_ctx* ctx, int n_blocks, const uint8_t* const* src, const size_t* src_len,
+                     uint8_t* const* dst, const size_t* dst_cap, int64_t* out_len);
+
+/* ---- device-resident batch calls (asynchronous on `stream`, a hipStream_t; NULL = default) ----
+ * d_src / d_dst / d_out_len are device pointers.  d_out_len[i] (int64) receives what
+ * mlz_encode / mlz_decode would have returned for block i.  `desc` is a host array (copied). */
+int mlz_encode_batch_device(mlz_ctx* ctx, void* stream, int level, const uint8_t* d_src, uint8_t* d_dst,
+                            const mlz_block_desc* desc, int n_blocks, int64_t* d_out_len);
+int mlz_decode_batch_device(mlz_ctx* ctx, void* stream, const uint8_t* d_src, uint8_t* d_dst,
+                            const mlz_block_desc* desc, int n_blocks, int64_t* d_out_len);
+
+/* ---- tuning / introspection (not part of the reference surface) ---- */
+#define MLZ_OPT_DECODE_ALGO 1  /* 0 = parallel (default), 1 = serial one-wave-per-block */
+#define MLZ_OPT_ENCODE_FAR 2   /* 0 = tile-local matches only, 1 = + far matches (default) */
+int mlz_set_option(mlz_ctx* ctx, int opt, int64_t value);
+/* Milliseconds spent in each kernel family during the last *_batch_device call, measured with
+ * HIP events on the caller's stream (only recorded when timing was enabled). */
+#define MLZ_TIMER_ENABLE 100
+int mlz_get_timers(mlz_ctx* ctx, float* ms, int cap); /* returns number of timers written */
+const char* mlz_timer_name(int idx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,266 @@
+"""Block API mirror of the reference (encode.go:74-244, decode.go:50-156) over the C ABI."""
+import ctypes as C
+import threading
+
+import numpy as np
+
+from . import _lib
+from ._lib import BlockDesc
+
+LevelUncompressed, LevelFastest, LevelBalanced = 0, 1, 2  # encode.go:25-43
+MaxBlockSize = 8 << 20  # minlz.go:84
+
+OPT_DECODE_ALGO, OPT_ENCODE_FAR, OPT_TIMING = 1, 2, 100
+
+
+class MinLZError(Exception):
+    code = 0
+
+
+class ErrCorrupt(MinLZError):
+    """minlz: corrupt input (decode.go:31)"""
+    code = 1
+
+
+class ErrTooLarge(MinLZError):
+    """minlz: decoded block is too large (decode.go:35)"""
+    code = 2
+
+
+class ErrUnsupported(MinLZError):
+    """minlz: unsupported input (decode.go:37)"""
+    code = 3
+
+
+class ErrInvalidLevel(MinLZError):
+    """minlz: invalid compression level (decode.go:39)"""
+    code = 4
+
+
+class ErrCRC(MinLZError):
+    """minlz: corrupt input, crc mismatch (decode.go:33)"""
+    code = 5
+
+
+class ErrHIP(MinLZError):
+    code = 7
+
+
+_ERRS = {1: ErrCorrupt, 2: ErrTooLarge, 3: ErrUnsupported, 4: ErrInvalidLevel, 5: ErrCRC, 7: ErrHIP}
+
+
+def _raise(code, ctx=None):
+    code = -code if code < 0 else code
+    msg = ""
+    if ctx is not None and code == 7:
+        msg = _lib.lib().mlz_last_error(ctx.handle).decode()
+    raise _ERRS.get(code, MinLZError)("minlz error %d %s" % (code, msg))
+
+
+class Context:
+    """One HIP device context (mlz_ctx). Thread-safe on the C side."""
+
+    def __init__(self, device=-1):
+        self.handle = C.c_void_p()
+        r = _lib.lib().mlz_init(device, C.byref(self.handle))
+        if r != 0:
+            raise ErrHIP("mlz_init failed (%d): no HIP device?" % r)
+
+    def close(self):
+        if self.handle:
+            _lib.lib().mlz_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_option(self, opt, value):
+        r = _lib.lib().mlz_set_option(self.handle, opt, int(value))
+        if r:
+            _raise(r, self)
+
+    def device_name(self):
+        buf = C.create_string_buffer(256)
+        _lib.lib().mlz_device_name(self.handle, buf, 256)
+        return buf.value.decode()
+
+    def timers(self):
+        arr = (C.c_float * 16)()
+        n = _lib.lib().mlz_get_timers(self.handle, arr, 16)
+        return {_lib.lib().mlz_timer_name(i).decode(): arr[i] for i in range(n) if arr[i] >= 0}
+
+    # ---- device-resident batch calls: pointers are raw device addresses (e.g. tensor.data_ptr()) ----
+    def encode_batch_device(self, stream, level, d_src, d_dst, descs, d_out_len):
+        arr = (BlockDesc * len(descs))(*descs) if not isinstance(descs, C.Array) else descs
+        r = _lib.lib().mlz_encode_batch_device(self.handle, stream, level, d_src, d_dst, arr, len(arr), d_out_len)
+        if r:
+            _raise(r, self)
+
+    def decode_batch_device(self, stream, d_src, d_dst, descs, d_out_len):
+        arr = (BlockDesc * len(descs))(*descs) if not isinstance(descs, C.Array) else descs
+        r = _lib.lib().mlz_decode_batch_device(self.handle, stream, d_src, d_dst, arr, len(arr), d_out_len)
+        if r:
+            _raise(r, self)
+
+
+_default = None
+_default_lock = threading.Lock()
+
+
+def default_context():
+    global _default
+    with _default_lock:
+        if _default is None:
+            _default = Context()
+        return _default
+
+
+def _np(b):
+    if isinstance(b, np.ndarray):
+        return np.ascontiguousarray(b, dtype=np.uint8)
+    return np.frombuffer(b, dtype=np.uint8)
+
+
+def _ptr(a):
+    return a.ctypes.data if a.size else None
+
+
+def MaxEncodedLen(n):
+    """encode.go:234-244"""
+    return _lib.lib().mlz_max_encoded_len(n) if n >= 0 else -1
+
+
+def DecodedLen(src):
+    """decode.go:107-110"""
+    a = _np(src)
+    r = _lib.lib().mlz_decoded_len(_ptr(a), a.size)
+    if r < 0:
+        _raise(r)
+    return r
+
+
+def IsMinLZ(src):
+    """decode.go:114-117 -> (ok, size); raises like the reference returns err."""
+    a = _np(src)
+    r = _lib.lib().mlz_decoded_len(_ptr(a), a.size)
+    if r < 0:
+        _raise(r)
+    return (a.size > 0 and a[0] == 0), r
+
+
+def Encode(src, level=LevelFastest, ctx=None):
+    """minlz.Encode(nil, src, level), encode.go:74-139."""
+    ctx = ctx or default_context()
+    a = _np(src)
+    cap_ = MaxEncodedLen(a.size)
+    if cap_ < 0:
+        raise ErrTooLarge()
+    out = np.empty(cap_, dtype=np.uint8)
+    r = _lib.lib().mlz_encode(ctx.handle, level, _ptr(a), a.size, out.ctypes.data, cap_)
+    if r < 0:
+        _raise(r, ctx)
+    return out[:r].tobytes()
+
+
+def AppendEncoded(dst, src, level=LevelFastest, ctx=None):
+    """encode.go:144-162"""
+    return bytes(dst) + Encode(src, level, ctx)
+
+
+def TryEncode(src, level=LevelFastest, ctx=None):
+    """encode.go:168-206: None when incompressible."""
+    a = _np(src)
+    if MaxEncodedLen(a.size) < 0 or a.size < 16 or level not in (LevelFastest, LevelBalanced):
+        return None
+    e = Encode(a, level, ctx)
+    if len(e) >= 2 and e[0] == 0 and e[1] == 0:
+        return None
+    return e if len(e) < a.size else None
+
+
+def Decode(src, ctx=None, guard=0):
+    """minlz.Decode(nil, src), decode.go:50-78."""
+    ctx = ctx or default_context()
+    a = _np(src)
+    n = DecodedLen(a)
+    out = np.full(n + guard, 0xA5, dtype=np.uint8)
+    if a.size and a[0] != 0 and not (a.size == 1):
+        raise ErrUnsupported("Snappy/S2 fallback block")
+    r = _lib.lib().mlz_decode(ctx.handle, _ptr(a), a.size, out.ctypes.data, n)
+    if guard and not (out[n:] == 0xA5).all():
+        raise AssertionError("decoder wrote past dst")
+    if r < 0:
+        _raise(r, ctx)
+    return out[:r].tobytes()
+
+
+def AppendDecoded(dst, src, ctx=None):
+    """decode.go:85-103"""
+    return bytes(dst) + Decode(src, ctx)
+
+
+def encode_block(src, level=LevelFastest, ctx=None):
+    """encodeBlock(dst, src) / WriterCustomEncoder contract (writer.go:1293-1304): tokens only; b'' = incompressible."""
+    ctx = ctx or default_context()
+    a = _np(src)
+    out = np.empty(a.size + 16, dtype=np.uint8)
+    r = _lib.lib().mlz_encode_block(ctx.handle, level, _ptr(a), a.size, out.ctypes.data, out.size)
+    if r < 0:
+        _raise(r, ctx)
+    return out[:r].tobytes()
+
+
+def decode_block(body, dlen, ctx=None):
+    """minLZDecode(dst[:dlen], body) (decode.go:178): returns (code, bytes)."""
+    ctx = ctx or default_context()
+    a = _np(body)
+    out = np.zeros(max(dlen, 1), dtype=np.uint8)
+    r = _lib.lib().mlz_decode_block(ctx.handle, _ptr(a), a.size, out.ctypes.data, dlen)
+    if r < 0:
+        _raise(r, ctx)
+    return r, out[:dlen].tobytes()
+
+
+def encode_batch(blocks, level=LevelFastest, ctx=None):
+    """mlz_encode_batch over a list of byte blocks -> list of encoded blocks."""
+    ctx = ctx or default_context()
+    arrs = [_np(b) for b in blocks]
+    n = len(arrs)
+    outs = [np.empty(max(MaxEncodedLen(a.size), 1), dtype=np.uint8) for a in arrs]
+    vp, sz = C.c_void_p, C.c_size_t
+    srcp = (vp * n)(*[_ptr(a) for a in arrs]); srcl = (sz * n)(*[a.size for a in arrs])
+    dstp = (vp * n)(*[o.ctypes.data for o in outs]); dstc = (sz * n)(*[o.size for o in outs])
+    ol = (C.c_int64 * n)()
+    r = _lib.lib().mlz_encode_batch(ctx.handle, level, n, srcp, srcl, dstp, dstc, ol)
+    if r:
+        _raise(r, ctx)
+    res = []
+    for i in range(n):
+        if ol[i] < 0:
+            _raise(ol[i], ctx)
+        res.append(outs[i][:ol[i]].tobytes())
+    return res
+
+
+def decode_batch(blocks, ctx=None):
+    ctx = ctx or default_context()
+    arrs = [_np(b) for b in blocks]
+    n = len(arrs)
+    lens = [DecodedLen(a) for a in arrs]
+    outs = [np.empty(max(l, 1), dtype=np.uint8) for l in lens]
+    vp, sz = C.c_void_p, C.c_size_t
+    srcp = (vp * n)(*[_ptr(a) for a in arrs]); srcl = (sz * n)(*[a.size for a in arrs])
+    dstp = (vp * n)(*[o.ctypes.data for o in outs]); dstc = (sz * n)(*lens)
+    ol = (C.c_int64 * n)()
+    r = _lib.lib().mlz_decode_batch(ctx.handle, n, srcp, srcl, dstp, dstc, ol)
+    if r:
+        _raise(r, ctx)
+    res = []
+    for i in range(n):
+        if ol[i] < 0:
+            _raise(ol[i], ctx)
+        res.append(outs[i][:ol[i]].tobytes())
+    return res

@@ -1,0 +1,500 @@
+// mlz_hip.hip — C ABI (include/minlz_hip.h) + launch logic of the MI355X MinLZ block codec.
+//
+// Built for gfx950 only:  hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC
+// No CPU codec lives in this library: every encode/decode call runs the HIP kernels, and a HIP
+// failure is reported as -MLZ_ERR_HIP (the Go wrapper then falls back to upstream's CPU path).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/minlz_hip.h"
+#include "mlz_format.h"
+#include "mlz_kernels.h"
+
+#include "mlz_encode.hip.inc"
+#include "mlz_decode_serial.hip.inc"
+#include "mlz_decode.hip.inc"
+
+using namespace mlz;
+
+namespace {
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    hipError_t ensure(size_t n) {
+        if (n <= cap) return hipSuccess;
+        if (p) { hipError_t e = hipFree(p); p = nullptr; cap = 0; if (e != hipSuccess) return e; }
+        size_t want = n + n / 4 + 4096;
+        hipError_t e = hipMalloc(&p, want);
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    template <class T> T* as() { return static_cast<T*>(p); }
+};
+
+enum { T_FAR = 0, T_ENC_TILES, T_ENC_LAYOUT, T_ENC_GATHER, T_DEC_PARSE, T_DEC_CHAIN, T_DEC_INDEX, T_DEC_EXEC, T_DEC_SERIAL, T_COUNT };
+const char* kTimerNames[T_COUNT] = {"enc_far_build", "enc_tiles", "enc_layout", "enc_gather", "dec_parse", "dec_chain", "dec_index", "dec_exec", "dec_serial"};
+
+}  // namespace
+
+struct mlz_ctx {
+    int device = 0;
+    std::mutex mu;
+    std::string err;
+    std::string dev_name;
+    hipStream_t stream = nullptr;  // used by the host-pointer calls
+    // descriptors
+    DevBuf d_blocks, d_tile_block, d_seg_block;
+    std::vector<BlockInfo> h_blocks, h_blocks_prev;
+    std::vector<uint32_t> h_tile_block, h_seg_block;
+    void* pinned = nullptr;
+    size_t pinned_cap = 0;
+    hipEvent_t upload_done = nullptr;
+    bool upload_pending = false;
+    // encode workspace
+    DevBuf d_scratch, d_tile_size, d_tile_out, d_flags, d_far;
+    // decode workspace
+    DevBuf d_dec;
+    // host-pointer staging
+    DevBuf d_in, d_out, d_len;
+    // options
+    int decode_algo = 0;
+    int encode_far = 1;
+    bool timing = false;
+    int debug_status = 0;
+    hipEvent_t ev[T_COUNT][2] = {};
+    bool ev_used[T_COUNT] = {};
+};
+
+namespace {
+
+#define HIPCHK(ctx, call)                                                                 \
+    do {                                                                                  \
+        hipError_t e_ = (call);                                                           \
+        if (e_ != hipSuccess) {                                                           \
+            (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_);               \
+            return -MLZ_ERR_HIP;                                                          \
+        }                                                                                 \
+    } while (0)
+
+struct Timer {
+    mlz_ctx* c; int id; hipStream_t s;
+    Timer(mlz_ctx* c_, int id_, hipStream_t s_) : c(c_), id(id_), s(s_) {
+        if (c->timing) { (void)hipEventRecord(c->ev[id][0], s); }
+    }
+    ~Timer() {
+        if (c->timing) { (void)hipEventRecord(c->ev[id][1], s); c->ev_used[id] = true; }
+    }
+};
+
+// Builds BlockInfo / tile map on the host and uploads them when they differ from the last call.
+int upload_blocks(mlz_ctx* c, hipStream_t st, const mlz_block_desc* desc, int n, bool tiles_from_dst, uint32_t* total_tiles, uint32_t* total_segs = nullptr) {
+    c->h_blocks.resize(n);
+    uint32_t tiles = 0, segs = 0;
+    for (int i = 0; i < n; i++) {
+        BlockInfo& b = c->h_blocks[i];
+        b.src_off = desc[i].src_off; b.src_len = desc[i].src_len; b.dst_off = desc[i].dst_off; b.dst_cap = desc[i].dst_cap;
+        uint64_t span = tiles_from_dst ? desc[i].dst_cap : desc[i].src_len;
+        if (span > kMaxBlockSize) span = tiles_from_dst ? kMaxBlockSize : 0;
+        b.first_tile = tiles;
+        b.n_tiles = uint32_t((span + kTile - 1) >> kTileLog);
+        tiles += b.n_tiles;
+        b.first_seg = segs;
+        b.n_segs = 0;
+        if (tiles_from_dst) {  // decode: segments of the token stream
+            uint64_t cl = std::min<uint64_t>(desc[i].src_len, uint64_t(kMaxBlockSize) + 16);
+            b.n_segs = uint32_t((cl + kSeg - 1) >> kSegLog);
+            segs += b.n_segs;
+        }
+    }
+    *total_tiles = tiles;
+    if (total_segs) *total_segs = segs;
+    const bool same = c->h_blocks_prev.size() == c->h_blocks.size() &&
+                      std::memcmp(c->h_blocks_prev.data(), c->h_blocks.data(), sizeof(BlockInfo) * n) == 0;
+    if (same) return 0;
+    c->h_tile_block.resize(tiles);
+    c->h_seg_block.resize(segs);
+    for (int i = 0; i < n; i++) {
+        for (uint32_t t = 0; t < c->h_blocks[i].n_tiles; t++) c->h_tile_block[c->h_blocks[i].first_tile + t] = uint32_t(i);
+        for (uint32_t t = 0; t < c->h_blocks[i].n_segs; t++) c->h_seg_block[c->h_blocks[i].first_seg + t] = uint32_t(i);
+    }
+    const size_t nb = sizeof(BlockInfo) * n, nt = sizeof(uint32_t) * tiles, ns = sizeof(uint32_t) * segs;
+    if (c->upload_pending) { HIPCHK(c, hipEventSynchronize(c->upload_done)); c->upload_pending = false; }
+    if (nb + nt + ns > c->pinned_cap) {
+        if (c->pinned) HIPCHK(c, hipHostFree(c->pinned));
+        c->pinned = nullptr;
+        c->pinned_cap = (nb + nt + ns) * 2 + 4096;
+        HIPCHK(c, hipHostMalloc(&c->pinned, c->pinned_cap, hipHostMallocDefault));
+    }
+    HIPCHK(c, c->d_blocks.ensure(nb + 64));
+    HIPCHK(c, c->d_tile_block.ensure(nt + 64));
+    HIPCHK(c, c->d_seg_block.ensure(ns + 64));
+    std::memcpy(c->pinned, c->h_blocks.data(), nb);
+    std::memcpy(static_cast<char*>(c->pinned) + nb, c->h_tile_block.data(), nt);
+    std::memcpy(static_cast<char*>(c->pinned) + nb + nt, c->h_seg_block.data(), ns);
+    if (nb) HIPCHK(c, hipMemcpyAsync(c->d_blocks.p, c->pinned, nb, hipMemcpyHostToDevice, st));
+    if (nt) HIPCHK(c, hipMemcpyAsync(c->d_tile_block.p, static_cast<char*>(c->pinned) + nb, nt, hipMemcpyHostToDevice, st));
+    if (ns) HIPCHK(c, hipMemcpyAsync(c->d_seg_block.p, static_cast<char*>(c->pinned) + nb + nt, ns, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipEventRecord(c->upload_done, st));
+    c->upload_pending = true;
+    c->h_blocks_prev = c->h_blocks;
+    return 0;
+}
+
+int encode_device_locked(mlz_ctx* c, hipStream_t st, int level, const uint8_t* d_src, uint8_t* d_dst, const mlz_block_desc* desc, int n,
+                         int64_t* d_out_len, bool with_header) {
+    if (level != MLZ_LEVEL_UNCOMPRESSED && level != MLZ_LEVEL_FASTEST && level != MLZ_LEVEL_BALANCED) return -MLZ_ERR_INVALID_LEVEL;
+    if (n <= 0) return 0;
+    HIPCHK(c, hipSetDevice(c->device));
+    uint32_t tiles = 0;
+    int r = upload_blocks(c, st, desc, n, false, &tiles);
+    if (r) return r;
+    HIPCHK(c, c->d_tile_size.ensure(sizeof(uint32_t) * (tiles + 1)));
+    HIPCHK(c, c->d_tile_out.ensure(sizeof(uint32_t) * (tiles + 1)));
+    HIPCHK(c, c->d_flags.ensure(sizeof(uint32_t) * n));
+    const BlockInfo* blocks = c->d_blocks.as<BlockInfo>();
+    const uint32_t* tile_block = c->d_tile_block.as<uint32_t>();
+    if (level != MLZ_LEVEL_UNCOMPRESSED && tiles > 0) {
+        HIPCHK(c, c->d_scratch.ensure(size_t(tiles) * kTileScratch));
+        uint64_t maxlen = 0;
+        for (int i = 0; i < n; i++) maxlen = std::max<uint64_t>(maxlen, std::min<uint64_t>(desc[i].src_len, kMaxBlockSize));
+        const uint32_t epochs = uint32_t((maxlen + (1u << kEpochLog) - 1) >> kEpochLog);
+        // LevelBalanced currently maps onto the same kernel with far matching forced on
+        // (DESIGN.md "Levels").
+        const bool far = (c->encode_far || level == MLZ_LEVEL_BALANCED) && maxlen > kTile;
+        if (far) {
+            Timer t(c, T_FAR, st);
+            const size_t words = (size_t(n) * (kLevels - 1) * epochs) << kFarBits;
+            HIPCHK(c, c->d_far.ensure(words * 4));
+            HIPCHK(c, hipMemsetAsync(c->d_far.p, 0xff, words * 4, st));
+            dim3 grid(std::max<uint32_t>(1, std::min<uint32_t>(512, uint32_t((maxlen / kFarStride + 255) / 256))), n);
+            hipLaunchKernelGGL(far_build_kernel, grid, dim3(256), 0, st, d_src, blocks, c->d_far.as<uint32_t>(), epochs);
+        }
+        {
+            Timer t(c, T_ENC_TILES, st);
+            if (far)
+                hipLaunchKernelGGL(encode_tiles_kernel<true>, dim3(tiles), dim3(64), 0, st, d_src, blocks, tile_block, c->d_scratch.as<uint8_t>(),
+                                   c->d_tile_size.as<uint32_t>(), c->d_far.as<uint32_t>(), epochs);
+            else
+                hipLaunchKernelGGL(encode_tiles_kernel<false>, dim3(tiles), dim3(64), 0, st, d_src, blocks, tile_block, c->d_scratch.as<uint8_t>(),
+                                   c->d_tile_size.as<uint32_t>(), (const uint32_t*)nullptr, epochs);
+        }
+    }
+    {
+        Timer t(c, T_ENC_LAYOUT, st);
+        hipLaunchKernelGGL(encode_layout_kernel, dim3(n), dim3(64), 0, st, blocks, c->d_tile_size.as<uint32_t>(), c->d_tile_out.as<uint32_t>(), d_dst,
+                           d_out_len, c->d_flags.as<uint32_t>(), level, with_header ? 1 : 0);
+    }
+    if (tiles > 0) {
+        Timer t(c, T_ENC_GATHER, st);
+        hipLaunchKernelGGL(encode_gather_kernel, dim3(tiles), dim3(256), 0, st, d_src, blocks, tile_block, c->d_scratch.as<uint8_t>(),
+                           c->d_tile_size.as<uint32_t>(), c->d_tile_out.as<uint32_t>(), d_dst, c->d_flags.as<uint32_t>(), with_header ? 1 : 0);
+    }
+    HIPCHK(c, hipGetLastError());
+    return 0;
+}
+
+int decode_parallel(mlz_ctx* c, hipStream_t st, const uint8_t* d_src, uint8_t* d_dst, const mlz_block_desc* desc, int n, int64_t* d_out_len,
+                    bool raw_body) {
+    uint32_t tiles = 0, segs = 0;
+    int r = upload_blocks(c, st, desc, n, true, &tiles, &segs);
+    if (r) return r;
+    // carve the workspace
+    auto al = [](size_t x) { return (x + 255) & ~size_t(255); };
+    const size_t o_dec = 0;
+    const size_t o_exit = o_dec + al(sizeof(DecBlock) * n);
+    const size_t o_entry = o_exit + al(size_t(segs) * kSeg * 4);
+    const size_t o_sout = o_entry + al(size_t(segs) * 4);
+    const size_t o_slast = o_sout + al(size_t(segs) * 4);
+    const size_t o_tstart = o_slast + al(size_t(segs) * 4);
+    const size_t o_done = o_tstart + al(size_t(tiles) * sizeof(TileStart));
+    const size_t o_ticket = o_done + al(size_t(tiles) * 4);
+    const size_t total = o_ticket + 256;
+    HIPCHK(c, c->d_dec.ensure(total));
+    uint8_t* ws = c->d_dec.as<uint8_t>();
+    DecBlock* dec = reinterpret_cast<DecBlock*>(ws + o_dec);
+    uint32_t* exit_tab = reinterpret_cast<uint32_t*>(ws + o_exit);
+    uint32_t* seg_entry = reinterpret_cast<uint32_t*>(ws + o_entry);
+    uint32_t* seg_out = reinterpret_cast<uint32_t*>(ws + o_sout);
+    uint32_t* seg_last = reinterpret_cast<uint32_t*>(ws + o_slast);
+    TileStart* tile_start = reinterpret_cast<TileStart*>(ws + o_tstart);
+    uint32_t* tile_done = reinterpret_cast<uint32_t*>(ws + o_done);
+    uint32_t* ticket = reinterpret_cast<uint32_t*>(ws + o_ticket);
+    const BlockInfo* blocks = c->d_blocks.as<BlockInfo>();
+    const uint32_t* tile_block = c->d_tile_block.as<uint32_t>();
+    const uint32_t* seg_block = c->d_seg_block.as<uint32_t>();
+    static bool attrs = false;
+    if (!attrs) {
+        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(dec_exit_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kSeg * 4 + kSeg + 64));
+        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(dec_index_a_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kIndexLds));
+        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(dec_index_c_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kIndexLds));
+        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(dec_exec_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kTile));
+        attrs = true;
+    }
+    {
+        Timer t(c, T_DEC_PARSE, st);
+        if (segs) HIPCHK(c, hipMemsetAsync(seg_entry, 0xff, size_t(segs) * 4, st));
+        HIPCHK(c, hipMemsetAsync(ws + o_done, 0, o_ticket + 256 - o_done, st));
+        hipLaunchKernelGGL(dec_header_kernel, dim3((n + 63) / 64), dim3(64), 0, st, d_src, blocks, dec, n, raw_body ? 1 : 0);
+        if (segs)
+            hipLaunchKernelGGL(dec_exit_kernel, dim3(segs), dim3(256), kSeg * 4 + kSeg + 64, st, d_src, blocks, seg_block, dec, exit_tab);
+    }
+    {
+        Timer t(c, T_DEC_CHAIN, st);
+        hipLaunchKernelGGL(dec_chain_kernel, dim3((n + 63) / 64), dim3(64), 0, st, blocks, dec, exit_tab, seg_entry, n);
+    }
+    {
+        Timer t(c, T_DEC_INDEX, st);
+        if (segs)
+            hipLaunchKernelGGL(dec_index_a_kernel, dim3(segs), dim3(256), kIndexLds, st, d_src, blocks, seg_block, dec, seg_entry, seg_out, seg_last);
+        hipLaunchKernelGGL(dec_index_b_kernel, dim3((n + 63) / 64), dim3(64), 0, st, blocks, dec, seg_out, seg_last, seg_entry, n);
+        if (segs)
+            hipLaunchKernelGGL(dec_index_c_kernel, dim3(segs), dim3(256), kIndexLds, st, d_src, blocks, seg_block, dec, seg_entry, seg_out, seg_last,
+                               tile_start);
+    }
+    {
+        Timer t(c, T_DEC_EXEC, st);
+        if (tiles)
+            hipLaunchKernelGGL(dec_exec_kernel, dim3(tiles), dim3(64), kTile, st, d_src, d_dst, blocks, tile_block, dec, tile_start, tile_done, ticket,
+                               tiles);
+        hipLaunchKernelGGL(dec_finish_kernel, dim3((n + 63) / 64), dim3(64), 0, st, dec, d_out_len, n, c->debug_status);
+    }
+    HIPCHK(c, hipGetLastError());
+    return 0;
+}
+
+int decode_device_locked(mlz_ctx* c, hipStream_t st, const uint8_t* d_src, uint8_t* d_dst, const mlz_block_desc* desc, int n, int64_t* d_out_len,
+                         bool raw_body) {
+    if (n <= 0) return 0;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (c->decode_algo == 1) {
+        uint32_t tiles = 0;
+        int r = upload_blocks(c, st, desc, n, true, &tiles);
+        if (r) return r;
+        Timer t(c, T_DEC_SERIAL, st);
+        hipLaunchKernelGGL(decode_serial_kernel, dim3(n), dim3(64), 0, st, d_src, d_dst, c->d_blocks.as<BlockInfo>(), d_out_len, raw_body ? 1 : 0);
+        HIPCHK(c, hipGetLastError());
+        return 0;
+    }
+    return decode_parallel(c, st, d_src, d_dst, desc, n, d_out_len, raw_body);
+}
+
+// ---- host-pointer plumbing: pack blocks into one device buffer, run, copy back ----
+int host_batch(mlz_ctx* c, bool encode, int level, int n, const uint8_t* const* src, const size_t* src_len, uint8_t* const* dst, const size_t* dst_cap,
+               int64_t* out_len, bool with_header, const size_t* decoded_len /* decode_block only */) {
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIPCHK(c, hipSetDevice(c->device));
+    std::vector<mlz_block_desc> desc(n);
+    size_t in_total = 0, out_total = 0;
+    for (int i = 0; i < n; i++) {
+        desc[i].src_off = in_total; desc[i].src_len = src_len[i];
+        in_total += (src_len[i] + 63) & ~size_t(63);
+        size_t cap = dst_cap[i];
+        if (encode) cap = std::min<size_t>(cap, size_t(kMaxBlockSize) + 16);
+        else if (decoded_len) cap = decoded_len[i];
+        else cap = std::min<size_t>(cap, kMaxBlockSize);
+        desc[i].dst_off = out_total; desc[i].dst_cap = cap;
+        out_total += (cap + 63) & ~size_t(63);
+    }
+    HIPCHK(c, c->d_in.ensure(in_total + 64));
+    HIPCHK(c, c->d_out.ensure(out_total + 64));
+    HIPCHK(c, c->d_len.ensure(sizeof(int64_t) * n));
+    hipStream_t st = c->stream;
+    for (int i = 0; i < n; i++)
+        if (src_len[i]) HIPCHK(c, hipMemcpyAsync(c->d_in.as<uint8_t>() + desc[i].src_off, src[i], src_len[i], hipMemcpyHostToDevice, st));
+    int r = encode ? encode_device_locked(c, st, level, c->d_in.as<uint8_t>(), c->d_out.as<uint8_t>(), desc.data(), n, c->d_len.as<int64_t>(), with_header)
+                   : decode_device_locked(c, st, c->d_in.as<uint8_t>(), c->d_out.as<uint8_t>(), desc.data(), n, c->d_len.as<int64_t>(), !with_header);
+    if (r) return r;
+    HIPCHK(c, hipMemcpyAsync(out_len, c->d_len.p, sizeof(int64_t) * n, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    for (int i = 0; i < n; i++) {
+        if (out_len[i] > 0) {
+            if (size_t(out_len[i]) > dst_cap[i]) { out_len[i] = -MLZ_ERR_DST_TOO_SMALL; continue; }
+            HIPCHK(c, hipMemcpyAsync(dst[i], c->d_out.as<uint8_t>() + desc[i].dst_off, size_t(out_len[i]), hipMemcpyDeviceToHost, st));
+        }
+    }
+    HIPCHK(c, hipStreamSynchronize(st));
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mlz_version(void) { return 1; }
+
+int mlz_init(int device, mlz_ctx** out) {
+    if (!out) return -MLZ_ERR_ARG;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count == 0) return -MLZ_ERR_HIP;
+    if (device < 0) { if (hipGetDevice(&device) != hipSuccess) return -MLZ_ERR_HIP; }
+    if (device >= count) return -MLZ_ERR_ARG;
+    if (hipSetDevice(device) != hipSuccess) return -MLZ_ERR_HIP;
+    mlz_ctx* c = new mlz_ctx();
+    c->device = device;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->dev_name = std::string(prop.name) + " (" + prop.gcnArchName + ")";
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return -MLZ_ERR_HIP; }
+    if (hipEventCreateWithFlags(&c->upload_done, hipEventDisableTiming) != hipSuccess) { delete c; return -MLZ_ERR_HIP; }
+    for (int i = 0; i < T_COUNT; i++)
+        for (int k = 0; k < 2; k++)
+            if (hipEventCreate(&c->ev[i][k]) != hipSuccess) { delete c; return -MLZ_ERR_HIP; }
+    *out = c;
+    return 0;
+}
+
+void mlz_destroy(mlz_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipDeviceSynchronize();
+    for (DevBuf* b : {&c->d_blocks, &c->d_tile_block, &c->d_seg_block, &c->d_scratch, &c->d_tile_size, &c->d_tile_out, &c->d_flags, &c->d_far, &c->d_dec, &c->d_in, &c->d_out, &c->d_len})
+        b->release();
+    if (c->pinned) (void)hipHostFree(c->pinned);
+    for (int i = 0; i < T_COUNT; i++)
+        for (int k = 0; k < 2; k++)
+            if (c->ev[i][k]) (void)hipEventDestroy(c->ev[i][k]);
+    if (c->upload_done) (void)hipEventDestroy(c->upload_done);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+const char* mlz_last_error(mlz_ctx* c) { return c ? c->err.c_str() : "null context"; }
+
+int mlz_device_name(mlz_ctx* c, char* buf, size_t cap) {
+    if (!c || !buf || cap == 0) return -MLZ_ERR_ARG;
+    std::snprintf(buf, cap, "%s", c->dev_name.c_str());
+    return 0;
+}
+
+int64_t mlz_max_encoded_len(uint64_t n) {
+    if (n > kMaxBlockSize) return -1;
+    if (n == 0) return 1;
+    return int64_t(n) + 2;
+}
+
+int64_t mlz_decoded_len(const uint8_t* src, size_t n) {
+    uint64_t body, dlen; int lits;
+    int e = parse_block_header(src, n, &body, &dlen, &lits);
+    if (e == 3) {  // non-MinLZ block: DecodedLen still reports the Snappy varint (decode.go:132-136)
+        uint64_t x = 0; uint32_t shift = 0;
+        for (size_t i = 0; i < n && i < 10; i++) {
+            uint8_t b = src[i];
+            if (b < 0x80) { x |= uint64_t(b) << shift; return x > 0xffffffffull ? -MLZ_ERR_CORRUPT : int64_t(x); }
+            x |= uint64_t(b & 0x7f) << shift; shift += 7;
+        }
+        return -MLZ_ERR_CORRUPT;
+    }
+    if (e) return -e;
+    return int64_t(dlen);
+}
+
+int64_t mlz_encode(mlz_ctx* c, int level, const uint8_t* src, size_t n, uint8_t* dst, size_t dst_cap) {
+    if (!c || (!src && n) || !dst) return -MLZ_ERR_ARG;
+    if (n > kMaxBlockSize) return -MLZ_ERR_TOO_LARGE;
+    if (int64_t(dst_cap) < mlz_max_encoded_len(n)) return -MLZ_ERR_DST_TOO_SMALL;
+    if (level != 0 && level != 1 && level != 2) return n < kMinNonLiteralBlock ? -MLZ_ERR_INVALID_LEVEL : -MLZ_ERR_INVALID_LEVEL;
+    int64_t out = 0;
+    int r = host_batch(c, true, level, 1, &src, &n, &dst, &dst_cap, &out, true, nullptr);
+    return r ? r : out;
+}
+
+int64_t mlz_encode_block(mlz_ctx* c, int level, const uint8_t* src, size_t n, uint8_t* dst, size_t dst_cap) {
+    if (!c || (!src && n) || !dst) return -MLZ_ERR_ARG;
+    if (n > kMaxBlockSize) return -MLZ_ERR_TOO_LARGE;
+    if (dst_cap < n) return -MLZ_ERR_DST_TOO_SMALL;
+    int64_t out = 0;
+    int r = host_batch(c, true, level, 1, &src, &n, &dst, &dst_cap, &out, false, nullptr);
+    return r ? r : out;
+}
+
+int64_t mlz_decode(mlz_ctx* c, const uint8_t* src, size_t n, uint8_t* dst, size_t dst_cap) {
+    if (!c || !src || (!dst && dst_cap)) return -MLZ_ERR_ARG;
+    int64_t dl = mlz_decoded_len(src, n);
+    uint64_t body, dlen; int lits;
+    int e = parse_block_header(src, n, &body, &dlen, &lits);
+    if (e) return -e;
+    if (dlen > dst_cap) return -MLZ_ERR_DST_TOO_SMALL;
+    (void)dl;
+    if (dlen == 0) return 0;
+    int64_t out = 0;
+    uint8_t* dp = dst; size_t cap = dst_cap;
+    int r = host_batch(c, false, 0, 1, &src, &n, &dp, &cap, &out, true, nullptr);
+    return r ? r : out;
+}
+
+int mlz_decode_block(mlz_ctx* c, const uint8_t* src, size_t clen, uint8_t* dst, size_t n) {
+    if (!c || (!src && clen) || (!dst && n)) return -MLZ_ERR_ARG;
+    if (n > kMaxBlockSize) return -MLZ_ERR_TOO_LARGE;
+    if (n == 0) return clen == 0 ? 0 : 1;
+    int64_t out = 0;
+    size_t cap = n;
+    int r = host_batch(c, false, 0, 1, &src, &clen, &dst, &cap, &out, false, &n);
+    if (r) return r;
+    return out == int64_t(n) ? 0 : 1;
+}
+
+int mlz_encode_batch(mlz_ctx* c, int level, int n, const uint8_t* const* src, const size_t* src_len, uint8_t* const* dst, const size_t* dst_cap,
+                     int64_t* out_len) {
+    if (!c || n < 0) return -MLZ_ERR_ARG;
+    if (n == 0) return 0;
+    if (level != 0 && level != 1 && level != 2) return -MLZ_ERR_INVALID_LEVEL;
+    return host_batch(c, true, level, n, src, src_len, dst, dst_cap, out_len, true, nullptr);
+}
+
+int mlz_decode_batch(mlz_ctx* c, int n, const uint8_t* const* src, const size_t* src_len, uint8_t* const* dst, const size_t* dst_cap, int64_t* out_len) {
+    if (!c || n < 0) return -MLZ_ERR_ARG;
+    if (n == 0) return 0;
+    return host_batch(c, false, 0, n, src, src_len, dst, dst_cap, out_len, true, nullptr);
+}
+
+int mlz_encode_batch_device(mlz_ctx* c, void* stream, int level, const uint8_t* d_src, uint8_t* d_dst, const mlz_block_desc* desc, int n,
+                            int64_t* d_out_len) {
+    if (!c || !desc || n < 0 || !d_out_len) return -MLZ_ERR_ARG;
+    std::lock_guard<std::mutex> lk(c->mu);
+    return encode_device_locked(c, static_cast<hipStream_t>(stream), level, d_src, d_dst, desc, n, d_out_len, true);
+}
+
+int mlz_decode_batch_device(mlz_ctx* c, void* stream, const uint8_t* d_src, uint8_t* d_dst, const mlz_block_desc* desc, int n, int64_t* d_out_len) {
+    if (!c || !desc || n < 0 || !d_out_len) return -MLZ_ERR_ARG;
+    std::lock_guard<std::mutex> lk(c->mu);
+    return decode_device_locked(c, static_cast<hipStream_t>(stream), d_src, d_dst, desc, n, d_out_len, false);
+}
+
+int mlz_set_option(mlz_ctx* c, int opt, int64_t value) {
+    if (!c) return -MLZ_ERR_ARG;
+    std::lock_guard<std::mutex> lk(c->mu);
+    switch (opt) {
+    case MLZ_OPT_DECODE_ALGO: c->decode_algo = int(value); return 0;
+    case MLZ_OPT_ENCODE_FAR: c->encode_far = int(value); return 0;
+    case 3: c->debug_status = int(value); return 0;  // debug: report failure sites in the error code
+    case MLZ_TIMER_ENABLE: c->timing = value != 0; for (bool& u : c->ev_used) u = false; return 0;
+    default: return -MLZ_ERR_ARG;
+    }
+}
+
+int mlz_get_timers(mlz_ctx* c, float* ms, int cap) {
+    if (!c || !ms) return -MLZ_ERR_ARG;
+    std::lock_guard<std::mutex> lk(c->mu);
+    int n = std::min<int>(cap, T_COUNT);
+    for (int i = 0; i < n; i++) {
+        ms[i] = -1.f;
+        if (c->ev_used[i]) {
+            if (hipEventSynchronize(c->ev[i][1]) != hipSuccess) continue;
+            float t = 0;
+            if (hipEventElapsedTime(&t, c->ev[i][0], c->ev[i][1]) == hipSuccess) ms[i] = t;
+        }
+    }
+    return n;
+}
+
+const char* mlz_timer_name(int idx) { return idx >= 0 && idx < T_COUNT ? kTimerNames[idx] : ""; }
+
+}  // extern "C"

@@ -1,0 +1,21 @@
+// mlz_kernels.h — device-side data structures shared between the kernels and the host API.
+#pragma once
+#include <stdint.h>
+
+namespace mlz {
+
+// Tile = the unit of intra-block parallelism (DESIGN.md "Tiles").  Each tile of a block is
+// encoded by one wavefront into an independent token sub-stream and decoded by one wavefront.
+constexpr int kTileLog = 16;
+constexpr uint32_t kTile = 1u << kTileLog;           // 64 KiB of uncompressed data
+constexpr uint32_t kTileScratch = kTile + kTile / 16 + 64;  // worst-case tokens per tile
+
+struct BlockInfo {
+    uint64_t src_off, src_len, dst_off, dst_cap;
+    uint32_t first_tile;  // index of this block's first tile in the batch-wide tile arrays
+    uint32_t n_tiles;
+    uint32_t first_seg;   // decode: index of this block's first token-stream segment
+    uint32_t n_segs;
+};
+
+}  // namespace mlz

@@ -1,0 +1,827 @@
+/*
+ * minlz_oracle.c — CPU restatement of the MinLZ block codec.  TEST INFRASTRUCTURE ONLY
+ * (see minlz_oracle.h for the rules and the pinning status).
+ *
+ * Every function cites the reference file:line it restates (paths relative to the upstream
+ * minio/minlz tree).  The code is written for clarity and exact behavioural agreement with the
+ * reference's pure-Go path, not for speed.
+ */
+#include "minlz_oracle.h"
+
+#include <pthread.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+/* ---- format constants (encode.go:44-59, minlz.go:93-100) ---- */
+#define MAX_COPY1_OFFSET 1024
+#define MIN_COPY2_OFFSET 64
+#define MAX_COPY2_OFFSET (MIN_COPY2_OFFSET + 65535)
+#define COPY2_LIT_MAX_LEN (7 + 4)
+#define MAX_COPY2_LITS 4
+#define MAX_COPY3_LITS 3
+#define MIN_COPY3_OFFSET 65536
+#define MAX_COPY3_OFFSET ((2 << 20) + 65535)
+#define INPUT_MARGIN 8                 /* encode.go:216 */
+#define MIN_NON_LITERAL_BLOCK_SIZE 16  /* encode.go:220 */
+
+#define TAG_LITERAL 0x00
+#define TAG_REPEAT 0x04
+#define TAG_COPY1 0x01
+#define TAG_COPY2 0x02
+#define TAG_COPY3 0x07
+#define TAG_COPY2_FUSED 0x03
+
+/* ---- unaligned little-endian loads/stores (unsafe_enabled.go:25-57) ---- */
+static inline uint32_t ld32(const uint8_t* p, size_t i) { uint32_t v; memcpy(&v, p + i, 4); return v; }
+static inline uint64_t ld64(const uint8_t* p, size_t i) { uint64_t v; memcpy(&v, p + i, 8); return v; }
+static inline uint16_t ld16(const uint8_t* p, size_t i) { uint16_t v; memcpy(&v, p + i, 2); return v; }
+static inline void st16(uint8_t* p, size_t i, uint16_t v) { memcpy(p + i, &v, 2); }
+static inline void st32(uint8_t* p, size_t i, uint32_t v) { memcpy(p + i, &v, 4); }
+
+/* ---- hashes (encode_l2.go:25-49, encode_l1.go:26-29) ---- */
+static inline uint32_t hash4(uint64_t u, unsigned h) { return ((uint32_t)u * 2654435761u) >> (32 - h); }
+static inline uint32_t hash5(uint64_t u, unsigned h) { return (uint32_t)(((u << 24) * 889523592379ull) >> (64 - h)); }
+static inline uint32_t hash6(uint64_t u, unsigned h) { return (uint32_t)(((u << 16) * 227718039650203ull) >> (64 - h)); }
+static inline uint32_t hash7(uint64_t u, unsigned h) { return (uint32_t)(((u << 8) * 58295818150454627ull) >> (64 - h)); }
+
+/* ======================================================================================
+ * Decoder
+ * ====================================================================================== */
+
+/* minLZDecodeGo, decode.go:178-622.  The reference has a fast loop (decode.go:188-359) and a
+ * checked tail loop (:362-611) with identical results; this restates the checked loop, which
+ * is the one that defines the error behaviour, cross-checked against
+ * internal/reference/decoder.go:142-369. */
+int mlzo_decode_body(uint8_t* dst, size_t dlen, const uint8_t* src, size_t slen) {
+    size_t d = 0, s = 0, length = 0, offset = 1; /* decode.go:184-185 */
+    while (s < slen) {
+        uint8_t b = src[s];
+        switch (b & 3) {
+        case 0: { /* literal / repeat, decode.go:367-431 */
+            unsigned x = b >> 3;
+            if (x < 29) { s += 1; length = x + 1; }
+            else if (x == 29) { s += 2; if (s > slen) return 1; length = (size_t)src[s - 1] + 30; }
+            else if (x == 30) { s += 3; if (s > slen) return 1; length = ((size_t)src[s - 2] | (size_t)src[s - 1] << 8) + 30; }
+            else { s += 4; if (s > slen) return 1; length = ((size_t)src[s - 3] | (size_t)src[s - 2] << 8 | (size_t)src[s - 1] << 16) + 30; }
+            if (b & 4) break; /* repeat: copy with previous offset */
+            if (length > dlen - d || length > slen - s) return 1; /* decode.go:412 */
+            memcpy(dst + d, src + s, length);
+            d += length; s += length;
+            continue;
+        }
+        case 1: /* copy1, decode.go:433-459 */
+            s += 2; if (s > slen) return 1;
+            length = (src[s - 2] >> 2) & 15;
+            offset = ((size_t)ld16(src, s - 2) >> 6) + 1;
+            if (length == 15) { s++; if (s > slen) return 1; length = (size_t)src[s - 1] + 18; }
+            else length += 4;
+            break;
+        case 2: /* copy2, decode.go:460-509 */
+            s += 3; if (s > slen) return 1;
+            length = src[s - 3] >> 2;
+            offset = (size_t)src[s - 2] | (size_t)src[s - 1] << 8;
+            if (length <= 60) length += 4;
+            else if (length == 61) { s += 1; if (s > slen) return 1; length = (size_t)src[s - 1] + 64; }
+            else if (length == 62) { s += 2; if (s > slen) return 1; length = ((size_t)src[s - 2] | (size_t)src[s - 1] << 8) + 64; }
+            else { s += 3; if (s > slen) return 1; length = ((size_t)src[s - 3] | (size_t)src[s - 2] << 8 | (size_t)src[s - 1] << 16) + 64; }
+            offset += MIN_COPY2_OFFSET;
+            break;
+        default: { /* fused copy2 / copy3, decode.go:510-582 */
+            s += 4; if (s > slen) return 1;
+            uint32_t val = ld32(src, s - 4);
+            size_t litlen = (val >> 3) & 3;
+            if (!(val & 4)) { /* fused copy2: 3-byte header */
+                length = 4 + ((val >> 5) & 7);
+                offset = ((val >> 8) & 65535) + MIN_COPY2_OFFSET;
+                s--; litlen++;
+            } else {
+                unsigned lt = (val >> 5) & 63;
+                offset = (size_t)(val >> 11) + MIN_COPY3_OFFSET;
+                if (lt < 61) length = lt + 4;
+                else if (lt == 61) { s += 1; if (s > slen) return 1; length = (size_t)src[s - 1] + 64; }
+                else if (lt == 62) { s += 2; if (s > slen) return 1; length = ((size_t)src[s - 2] | (size_t)src[s - 1] << 8) + 64; }
+                else { s += 3; if (s > slen) return 1; length = ((size_t)src[s - 3] | (size_t)src[s - 2] << 8 | (size_t)src[s - 1] << 16) + 64; }
+            }
+            if (litlen > 0) { /* literals come BEFORE the copy, decode.go:568-580 */
+                if (litlen > dlen - d || s + litlen > slen) return 1;
+                memcpy(dst + d, src + s, litlen);
+                d += litlen; s += litlen;
+            }
+            break;
+        }
+        }
+        /* doCopy2, decode.go:584-610 */
+        if (offset == 0 || d < offset || length > dlen - d) return 1;
+        if (offset > length) {
+            memcpy(dst + d, dst + d - offset, length);
+        } else { /* forward byte-by-byte: pattern replicate */
+            for (size_t i = 0; i < length; i++) dst[d + i] = dst[d - offset + i];
+        }
+        d += length;
+    }
+    return d == dlen ? 0 : 1; /* decode.go:615 */
+}
+
+/* binary.Uvarint as used by decodedLen (decode.go:160-171): returns header length, 0 = need
+ * more input, <0 = overflow. */
+static int uvarint(const uint8_t* src, size_t slen, uint64_t* out) {
+    uint64_t x = 0; unsigned shift = 0;
+    for (size_t i = 0; i < slen; i++) {
+        uint8_t b = src[i];
+        if (i == 10) return -(int)(i + 1); /* MaxVarintLen64 overflow */
+        if (b < 0x80) {
+            if (i == 9 && b > 1) return -(int)(i + 1);
+            *out = x | (uint64_t)b << shift;
+            return (int)i + 1;
+        }
+        x |= (uint64_t)(b & 0x7f) << shift;
+        shift += 7;
+    }
+    *out = 0;
+    return 0;
+}
+
+static int put_uvarint(uint8_t* dst, uint64_t v) {
+    int i = 0;
+    while (v >= 0x80) { dst[i++] = (uint8_t)v | 0x80; v >>= 7; }
+    dst[i++] = (uint8_t)v;
+    return i;
+}
+
+/* decodedLen, decode.go:160-171 */
+static int decoded_len_raw(const uint8_t* src, size_t slen, size_t* v, size_t* hdr) {
+    uint64_t x; int n = uvarint(src, slen, &x);
+    if (n <= 0 || x > 0xffffffffull) return MLZO_ERR_CORRUPT;
+    *v = (size_t)x; *hdr = (size_t)n;
+    return MLZO_OK;
+}
+
+/* isMinLZ, decode.go:120-156 */
+int mlzo_is_minlz(const uint8_t* src, size_t slen, int* is_mlz, int* literals, size_t* body_off, size_t* size) {
+    *is_mlz = 0; *literals = 0; *body_off = 0; *size = 0;
+    if (slen <= 1) {
+        if (slen == 0) return MLZO_ERR_CORRUPT;
+        if (src[0] == 0) { *is_mlz = 1; *literals = 1; *body_off = 1; *size = 0; return MLZO_OK; }
+    }
+    if (src[0] != 0) { /* Snappy / S2 block: size is reported, decoding is out of scope */
+        size_t v, h; int e = decoded_len_raw(src, slen, &v, &h);
+        if (e) return e;
+        *size = v; return MLZO_OK;
+    }
+    size_t v, h; int e = decoded_len_raw(src + 1, slen - 1, &v, &h);
+    if (e) return e;
+    if (v > MLZO_MAX_BLOCK_SIZE) return MLZO_ERR_TOO_LARGE;
+    size_t off = 1 + h, rest = slen - off;
+    if (rest == 0) return MLZO_ERR_CORRUPT;
+    if (v == 0) { *is_mlz = 1; *literals = 1; *body_off = off; *size = rest; return MLZO_OK; }
+    if (v < rest) { *body_off = off; *size = v; return MLZO_ERR_CORRUPT; }
+    *is_mlz = 1; *body_off = off; *size = v;
+    return MLZO_OK;
+}
+
+int mlzo_decoded_len(const uint8_t* src, size_t slen, size_t* dlen) {
+    int a, b; size_t off;
+    return mlzo_is_minlz(src, slen, &a, &b, &off, dlen);
+}
+
+/* Decode, decode.go:50-78 */
+int mlzo_decode(const uint8_t* src, size_t slen, uint8_t* dst, size_t dcap, size_t* dlen) {
+    int is_mlz, lits; size_t off, size;
+    *dlen = 0;
+    int e = mlzo_is_minlz(src, slen, &is_mlz, &lits, &off, &size);
+    if (e) return e;
+    if (lits) {
+        if (size > dcap) return MLZO_ERR_DST_TOO_SMALL;
+        memcpy(dst, src + off, size); *dlen = size; return MLZO_OK;
+    }
+    if (!is_mlz) return MLZO_ERR_UNSUPPORTED; /* decode.go:59-68 S2 fallback: out of scope */
+    if (size > dcap) return MLZO_ERR_DST_TOO_SMALL;
+    *dlen = size;
+    if (mlzo_decode_body(dst, size, src + off, slen - off) != 0) return MLZO_ERR_CORRUPT;
+    return MLZO_OK;
+}
+
+/* ======================================================================================
+ * Emitters
+ * ====================================================================================== */
+
+/* emitLiteral, asm_none.go:84-122 */
+size_t mlzo_emit_literal(uint8_t* dst, const uint8_t* lit, size_t len) {
+    if (len == 0) return 0;
+    size_t i, n = len - 1;
+    if (n < 29) { dst[0] = (uint8_t)(n << 3) | TAG_LITERAL; i = 1; }
+    else if (n < (1 << 8) + 29) { dst[1] = (uint8_t)(n - 29); dst[0] = 29 << 3 | TAG_LITERAL; i = 2; }
+    else if (n < (1 << 16) + 29) { n -= 29; dst[2] = (uint8_t)(n >> 8); dst[1] = (uint8_t)n; dst[0] = 30 << 3 | TAG_LITERAL; i = 3; }
+    else { n -= 29; dst[3] = (uint8_t)(n >> 16); dst[2] = (uint8_t)(n >> 8); dst[1] = (uint8_t)n; dst[0] = 31 << 3 | TAG_LITERAL; i = 4; }
+    memcpy(dst + i, lit, len);
+    return i + len;
+}
+
+/* emitRepeat, asm_none.go:125-156 */
+size_t mlzo_emit_repeat(uint8_t* dst, size_t length) {
+    if (length < 30) { dst[0] = (uint8_t)((length - 1) << 3) | TAG_REPEAT; return 1; }
+    length -= 30;
+    if (length < 256) { dst[1] = (uint8_t)length; dst[0] = 29 << 3 | TAG_REPEAT; return 2; }
+    if (length < 65536) { dst[2] = (uint8_t)(length >> 8); dst[1] = (uint8_t)length; dst[0] = 30 << 3 | TAG_REPEAT; return 3; }
+    dst[3] = (uint8_t)(length >> 16); dst[2] = (uint8_t)(length >> 8); dst[1] = (uint8_t)length; dst[0] = 31 << 3 | TAG_REPEAT;
+    return 4;
+}
+
+/* encodeCopy3, asm_none.go:160-200 */
+static size_t encode_copy3(uint8_t* dst, size_t offset, size_t length, size_t lits) {
+    length -= 4;
+    uint32_t enc = (uint32_t)(offset - 65536) << 11 | TAG_COPY3 | (uint32_t)(lits << 3);
+    if (length <= 60) { enc |= (uint32_t)(length << 5); st32(dst, 0, enc); return 4; }
+    length -= 60;
+    if (length < 256) { dst[4] = (uint8_t)length; enc |= 61 << 5; st32(dst, 0, enc); return 5; }
+    if (length < 65536) { enc |= 62 << 5; dst[5] = (uint8_t)(length >> 8); dst[4] = (uint8_t)length; st32(dst, 0, enc); return 6; }
+    enc |= 63 << 5; dst[6] = (uint8_t)(length >> 16); dst[5] = (uint8_t)(length >> 8); dst[4] = (uint8_t)length; st32(dst, 0, enc);
+    return 7;
+}
+
+/* encodeCopy2, encode.go:247-282 */
+static size_t encode_copy2(uint8_t* dst, size_t offset, size_t length) {
+    length -= 4; offset -= MIN_COPY2_OFFSET;
+    st16(dst, 1, (uint16_t)offset);
+    if (length <= 60) { dst[0] = (uint8_t)(length << 2) | TAG_COPY2; return 3; }
+    length -= 60;
+    if (length < 256) { dst[3] = (uint8_t)length; dst[0] = 61 << 2 | TAG_COPY2; return 4; }
+    if (length < 65536) { dst[4] = (uint8_t)(length >> 8); dst[3] = (uint8_t)length; dst[0] = 62 << 2 | TAG_COPY2; return 5; }
+    dst[5] = (uint8_t)(length >> 16); dst[4] = (uint8_t)(length >> 8); dst[3] = (uint8_t)length; dst[0] = 63 << 2 | TAG_COPY2;
+    return 6;
+}
+
+/* emitCopy, asm_none.go:207-278 */
+size_t mlzo_emit_copy(uint8_t* dst, size_t offset, size_t length) {
+    if (offset > MAX_COPY2_OFFSET) return encode_copy3(dst, offset, length, 0);
+    if (offset <= MAX_COPY1_OFFSET) {
+        offset--;
+        if (length < 15 + 4) { st16(dst, 0, (uint16_t)(offset << 6) | (uint16_t)((length - 4) << 2) | TAG_COPY1); return 2; }
+        if (length < 256 + 18) { st16(dst, 0, (uint16_t)(offset << 6) | (15 << 2 | TAG_COPY1)); dst[2] = (uint8_t)(length - 18); return 3; }
+        st16(dst, 0, (uint16_t)(offset << 6) | (14 << 2) | TAG_COPY1); /* copy1 of 18 + repeat */
+        return 2 + mlzo_emit_repeat(dst + 2, length - 18);
+    }
+    return encode_copy2(dst, offset, length);
+}
+
+/* emitCopyLits2, asm_none.go:284-308 */
+size_t mlzo_emit_copy_lits2(uint8_t* dst, const uint8_t* lits, size_t nlits, size_t offset, size_t length) {
+    offset -= MIN_COPY2_OFFSET;
+    length -= 4;
+    const size_t max_raw = COPY2_LIT_MAX_LEN - 4;
+    st16(dst, 1, (uint16_t)offset);
+    if (length > max_raw) {
+        dst[0] = TAG_COPY2_FUSED | (uint8_t)(max_raw << 5) | (uint8_t)((nlits - 1) << 3);
+        memcpy(dst + 3, lits, nlits);
+        size_t n = nlits + 3;
+        return n + mlzo_emit_repeat(dst + n, length - max_raw);
+    }
+    dst[0] = TAG_COPY2_FUSED | (uint8_t)(length << 5) | (uint8_t)((nlits - 1) << 3);
+    memcpy(dst + 3, lits, nlits);
+    return nlits + 3;
+}
+
+/* emitCopyLits3, asm_none.go:313-323 */
+size_t mlzo_emit_copy_lits3(uint8_t* dst, const uint8_t* lits, size_t nlits, size_t offset, size_t length) {
+    size_t n = encode_copy3(dst, offset, length, nlits);
+    memcpy(dst + n, lits, nlits);
+    return n + nlits;
+}
+
+/* ======================================================================================
+ * Encoders
+ * ====================================================================================== */
+
+/* MaxEncodedLen, encode.go:234-244 */
+long mlzo_max_encoded_len(size_t n) {
+    if (n > MLZO_MAX_BLOCK_SIZE) return -1;
+    if (n == 0) return 1;
+    return (long)n + 2;
+}
+
+static inline int ctz64(uint64_t v) { return __builtin_ctzll(v); }
+
+/* Forward extension used by L1 (encode_l1.go:181-188): 8 bytes at a time while s <= len-8. */
+static inline long extend8(const uint8_t* src, long n, long s, long cand) {
+    while (s <= n - 8) {
+        uint64_t diff = ld64(src, s) ^ ld64(src, cand);
+        if (diff) { s += ctz64(diff) >> 3; break; }
+        s += 8; cand += 8;
+    }
+    return s;
+}
+
+/* Forward extension used by L2 (encode_l2.go:236-251): runs to the very end of src. */
+static inline long extend_full(const uint8_t* src, long n, long s, long cand) {
+    while (s < n) {
+        if (n - s < 8) {
+            if (src[s] == src[cand]) { s++; cand++; continue; }
+            break;
+        }
+        uint64_t diff = ld64(src, s) ^ ld64(src, cand);
+        if (diff) { s += ctz64(diff) >> 3; break; }
+        s += 8; cand += 8;
+    }
+    return s;
+}
+
+/*
+ * L1 "Fastest".  encodeBlockGo (encode_l1.go:39-283; BIG=1: hash6, 15 bits, u32 entries,
+ * skipLog 6, <=3 fused literals, copy3 allowed, minSrcPos window check) and encodeBlockGo64K
+ * (encode_l1.go:285-524; BIG=0: hash5, 13 bits, u16 entries, skipLog 5, <=4 fused literals).
+ */
+#define DEFINE_L1(NAME, BIG, TBITS, TTYPE, HASH, SKIPLOG, MAXLITS)                                        \
+    static size_t NAME(uint8_t* dst, const uint8_t* src, long n) {                                         \
+        TTYPE* table = (TTYPE*)calloc((size_t)1 << TBITS, sizeof(TTYPE));                                  \
+        long sLimit = n - INPUT_MARGIN;                                                                    \
+        long dstLimit = n - (n >> 5) - 6;                                                                  \
+        long nextEmit = 0, s = 1, d = 0, repeat = 1;                                                       \
+        uint64_t cv = ld64(src, s);                                                                        \
+        for (;;) {                                                                                         \
+            long candidate = 0;                                                                            \
+            for (;;) {                                                                                     \
+                long nextS = s + ((s - nextEmit) >> SKIPLOG) + 4;                                          \
+                if (nextS > sLimit) goto emit_remainder;                                                   \
+                long minSrcPos = BIG ? s - MAX_COPY3_OFFSET : 0;                                           \
+                uint32_t h0 = HASH(cv, TBITS), h1 = HASH(cv >> 8, TBITS);                                  \
+                candidate = (long)table[h0];                                                               \
+                long candidate2 = (long)table[h1];                                                         \
+                table[h0] = (TTYPE)s;                                                                      \
+                table[h1] = (TTYPE)(s + 1);                                                                \
+                uint32_t h2 = HASH(cv >> 16, TBITS);                                                       \
+                /* repeat check one byte ahead (checkRep = 1) */                                           \
+                if ((uint32_t)(cv >> 8) == ld32(src, s - repeat + 1)) {                                    \
+                    long base = s + 1;                                                                     \
+                    for (long i = base - repeat; base > nextEmit && i > 0 && src[i - 1] == src[base - 1];) { i--; base--; } \
+                    if (d + (base - nextEmit) > dstLimit) { free(table); return 0; }                       \
+                    d += mlzo_emit_literal(dst + d, src + nextEmit, base - nextEmit);                      \
+                    long cand = s - repeat + 4 + 1;                                                        \
+                    s += 4 + 1;                                                                            \
+                    while (s <= sLimit) {                                                                  \
+                        uint64_t diff = ld64(src, s) ^ ld64(src, cand);                                    \
+                        if (diff) { s += ctz64(diff) >> 3; break; }                                        \
+                        s += 8; cand += 8;                                                                 \
+                    }                                                                                      \
+                    d += mlzo_emit_repeat(dst + d, s - base);                                              \
+                    nextEmit = s;                                                                          \
+                    if (s >= sLimit) goto emit_remainder;                                                  \
+                    cv = ld64(src, s);                                                                     \
+                    continue;                                                                              \
+                }                                                                                          \
+                if (candidate >= minSrcPos && (uint32_t)cv == ld32(src, candidate)) break;                 \
+                candidate = (long)table[h2];                                                               \
+                if (candidate2 >= minSrcPos && (uint32_t)(cv >> 8) == ld32(src, candidate2)) {             \
+                    table[h2] = (TTYPE)(s + 2);                                                            \
+                    candidate = candidate2; s++;                                                           \
+                    break;                                                                                 \
+                }                                                                                          \
+                table[h2] = (TTYPE)(s + 2);                                                                \
+                if (candidate >= minSrcPos && (uint32_t)(cv >> 16) == ld32(src, candidate)) { s += 2; break; } \
+                cv = ld64(src, nextS);                                                                     \
+                s = nextS;                                                                                 \
+            }                                                                                              \
+            while (candidate > 0 && s > nextEmit && src[candidate - 1] == src[s - 1]) { candidate--; s--; } \
+            long base = s;                                                                                 \
+            repeat = base - candidate;                                                                     \
+            s = extend8(src, n, s + 4, candidate + 4);                                                     \
+            long length = s - base;                                                                        \
+            if (nextEmit != base) {                                                                        \
+                if (base - nextEmit > MAXLITS || repeat < MIN_COPY2_OFFSET) {                              \
+                    if (d + (s - nextEmit) > dstLimit) { free(table); return 0; }                          \
+                    d += mlzo_emit_literal(dst + d, src + nextEmit, base - nextEmit);                      \
+                    d += mlzo_emit_copy(dst + d, repeat, length);                                          \
+                } else if (!BIG || repeat <= MAX_COPY2_OFFSET) {                                           \
+                    d += mlzo_emit_copy_lits2(dst + d, src + nextEmit, base - nextEmit, repeat, length);   \
+                } else {                                                                                   \
+                    d += mlzo_emit_copy_lits3(dst + d, src + nextEmit, base - nextEmit, repeat, length);   \
+                }                                                                                          \
+            } else {                                                                                       \
+                d += mlzo_emit_copy(dst + d, repeat, length);                                              \
+            }                                                                                              \
+            for (;;) { /* immediate re-match loop */                                                       \
+                nextEmit = s;                                                                              \
+                if (s >= sLimit) goto emit_remainder;                                                      \
+                uint64_t x = ld64(src, s - 2);                                                             \
+                if (d > dstLimit) { free(table); return 0; }                                               \
+                uint32_t m2 = HASH(x, TBITS);                                                              \
+                x >>= 16;                                                                                  \
+                uint32_t cur = HASH(x, TBITS);                                                             \
+                candidate = (long)table[cur];                                                              \
+                table[m2] = (TTYPE)(s - 2);                                                                \
+                table[cur] = (TTYPE)s;                                                                     \
+                if ((BIG && s - candidate > MAX_COPY3_OFFSET) || (uint32_t)x != ld32(src, candidate)) {    \
+                    cv = ld64(src, s + 1);                                                                 \
+                    s++;                                                                                   \
+                    break;                                                                                 \
+                }                                                                                          \
+                repeat = s - candidate;                                                                    \
+                base = s;                                                                                  \
+                s = extend8(src, n, s + 4, candidate + 4);                                                 \
+                d += mlzo_emit_copy(dst + d, repeat, s - base);                                            \
+            }                                                                                              \
+        }                                                                                                  \
+    emit_remainder:                                                                                        \
+        if (nextEmit < n) {                                                                                \
+            if (d + n - nextEmit > dstLimit) { free(table); return 0; }                                    \
+            d += mlzo_emit_literal(dst + d, src + nextEmit, n - nextEmit);                                 \
+        }                                                                                                  \
+        free(table);                                                                                       \
+        return (size_t)d;                                                                                  \
+    }
+
+DEFINE_L1(l1_big, 1, 15, uint32_t, hash6, 6, MAX_COPY3_LITS)
+DEFINE_L1(l1_64k, 0, 13, uint16_t, hash5, 5, MAX_COPY2_LITS)
+
+/* encodeBlock, asm_none.go:51-59 */
+size_t mlzo_encode_block_l1(uint8_t* dst, const uint8_t* src, size_t n) {
+    if (n < MIN_NON_LITERAL_BLOCK_SIZE) return 0;
+    if (n <= 65536) return l1_64k(dst, src, (long)n);
+    return l1_big(dst, src, (long)n);
+}
+
+/*
+ * L2 "Balanced".  encodeBlockBetterGo (encode_l2.go:61-338; BIG=1: long hash7/17 bits, short
+ * hash4/14 bits, u32) and encodeBlockBetterGo64K (encode_l2.go:343-596; BIG=0: hash6/15,
+ * hash4/12, u16, no window checks, no far-short-match rejection).
+ */
+#define DEFINE_L2(NAME, BIG, LBITS, SBITS, TTYPE, LHASH)                                                   \
+    static size_t NAME(uint8_t* dst, const uint8_t* src, long n) {                                         \
+        long sLimit = n - INPUT_MARGIN;                                                                    \
+        TTYPE* lTable = (TTYPE*)calloc((size_t)1 << LBITS, sizeof(TTYPE));                                 \
+        TTYPE* sTable = (TTYPE*)calloc((size_t)1 << SBITS, sizeof(TTYPE));                                 \
+        long dstLimit = n - (n >> 5) - 6;                                                                  \
+        long nextEmit = 0, s = 1, d = 0, repeat = 1;                                                       \
+        uint64_t cv = ld64(src, s);                                                                        \
+        size_t ret = 0;                                                                                    \
+        for (;;) {                                                                                         \
+            long candidateL = 0, nextS = 0;                                                                \
+            for (;;) {                                                                                     \
+                nextS = s + ((s - nextEmit) >> 7) + 1;                                                     \
+                if (nextS > sLimit) goto emit_remainder;                                                   \
+                long minSrcPos = s - MAX_COPY3_OFFSET + 1;                                                 \
+                uint32_t hL = LHASH(cv, LBITS), hS = hash4(cv, SBITS);                                     \
+                candidateL = (long)lTable[hL];                                                             \
+                long candidateS = (long)sTable[hS];                                                        \
+                lTable[hL] = (TTYPE)s;                                                                     \
+                sTable[hS] = (TTYPE)s;                                                                     \
+                uint64_t valLong = ld64(src, candidateL), valShort = ld64(src, candidateS);                \
+                if ((!BIG || candidateL > minSrcPos) && cv == valLong) break;                              \
+                /* repeat: 4 bytes at s+1 (checkRep = 1, wantRepeatBytes = 4) */                           \
+                const uint64_t repeatMask = 0xffffffffull << 8;                                            \
+                if (repeat > 0 && (cv & repeatMask) == (ld64(src, s - repeat) & repeatMask)) {             \
+                    long base = s + 1;                                                                     \
+                    for (long i = base - repeat; base > nextEmit && i > 0 && src[i - 1] == src[base - 1];) { i--; base--; } \
+                    if (d + (base - nextEmit) > dstLimit) goto done;                                       \
+                    d += mlzo_emit_literal(dst + d, src + nextEmit, base - nextEmit);                      \
+                    long cand = s - repeat + 4 + 1;                                                        \
+                    s = extend_full(src, n, s + 4 + 1, cand);                                              \
+                    d += mlzo_emit_repeat(dst + d, s - base);                                              \
+                    nextEmit = s;                                                                          \
+                    if (s >= sLimit) goto emit_remainder;                                                  \
+                    long index0 = base + 1, index1 = s - 2;                                                \
+                    while (index0 < index1) {                                                              \
+                        uint64_t cv0 = ld64(src, index0), cv1 = ld64(src, index1);                         \
+                        lTable[LHASH(cv0, LBITS)] = (TTYPE)index0;                                         \
+                        sTable[hash4(cv0 >> 8, SBITS)] = (TTYPE)(index0 + 1);                              \
+                        lTable[LHASH(cv1, LBITS)] = (TTYPE)index1;                                         \
+                        sTable[hash4(cv1 >> 8, SBITS)] = (TTYPE)(index1 + 1);                              \
+                        index0 += 2; index1 -= 2;                                                          \
+                    }                                                                                      \
+                    cv = ld64(src, s);                                                                     \
+                    continue;                                                                              \
+                }                                                                                          \
+                if ((!BIG || candidateL >= minSrcPos) && (uint32_t)cv == (uint32_t)valLong) break;         \
+                if ((!BIG || candidateS >= minSrcPos) && (uint32_t)cv == (uint32_t)valShort) {             \
+                    hL = LHASH(cv >> 8, LBITS);                                                            \
+                    candidateL = (long)lTable[hL];                                                         \
+                    lTable[hL] = (TTYPE)(s + 1);                                                           \
+                    if ((!BIG || candidateL > minSrcPos) && (uint32_t)(cv >> 8) == ld32(src, candidateL)) { s++; break; } \
+                    candidateL = candidateS;                                                               \
+                    break;                                                                                 \
+                }                                                                                          \
+                cv = ld64(src, nextS);                                                                     \
+                s = nextS;                                                                                 \
+            }                                                                                              \
+            while (candidateL > 0 && s > nextEmit && src[candidateL - 1] == src[s - 1]) { candidateL--; s--; } \
+            if (d + (s - nextEmit) > dstLimit) goto done;                                                  \
+            long base = s, offset = base - candidateL;                                                     \
+            s = extend_full(src, n, s + 4, candidateL + 4);                                                \
+            if (BIG && offset > 65535 && s - base <= 4 && repeat != offset) {                              \
+                s = nextS + 1;                                                                             \
+                if (s >= sLimit) goto emit_remainder;                                                      \
+                cv = ld64(src, s);                                                                         \
+                continue;                                                                                  \
+            }                                                                                              \
+            long nl = base - nextEmit;                                                                     \
+            if (nl > 0) {                                                                                  \
+                if (!BIG || offset <= MAX_COPY2_OFFSET) {                                                  \
+                    if (nl > MAX_COPY2_LITS || offset < 64) {                                              \
+                        d += mlzo_emit_literal(dst + d, src + nextEmit, nl);                               \
+                        d += mlzo_emit_copy(dst + d, offset, s - base);                                    \
+                    } else d += mlzo_emit_copy_lits2(dst + d, src + nextEmit, nl, offset, s - base);       \
+                } else {                                                                                   \
+                    if (nl > MAX_COPY3_LITS) {                                                             \
+                        d += mlzo_emit_literal(dst + d, src + nextEmit, nl);                               \
+                        d += mlzo_emit_copy(dst + d, offset, s - base);                                    \
+                    } else d += mlzo_emit_copy_lits3(dst + d, src + nextEmit, nl, offset, s - base);       \
+                }                                                                                          \
+            } else d += mlzo_emit_copy(dst + d, offset, s - base);                                         \
+            repeat = offset;                                                                               \
+            nextEmit = s;                                                                                  \
+            if (s >= sLimit) goto emit_remainder;                                                          \
+            if (d > dstLimit) goto done;                                                                   \
+            long index0 = base + 1, index1 = s - 2;                                                        \
+            uint64_t cv0 = ld64(src, index0), cv1 = ld64(src, index1);                                     \
+            lTable[LHASH(cv0, LBITS)] = (TTYPE)index0;                                                     \
+            sTable[hash4(cv0 >> 8, SBITS)] = (TTYPE)(index0 + 1);                                          \
+            lTable[LHASH(cv1, LBITS)] = (TTYPE)index1;                                                     \
+            sTable[hash4(cv1 >> 8, SBITS)] = (TTYPE)(index1 + 1);                                          \
+            index0 += 1; index1 -= 1;                                                                      \
+            cv = ld64(src, s);                                                                             \
+            long index2 = (index0 + index1 + 1) >> 1;                                                      \
+            while (index2 < index1) {                                                                      \
+                lTable[LHASH(ld64(src, index0), LBITS)] = (TTYPE)index0;                                   \
+                lTable[LHASH(ld64(src, index2), LBITS)] = (TTYPE)index2;                                   \
+                index0 += 2; index2 += 2;                                                                  \
+            }                                                                                              \
+        }                                                                                                  \
+    emit_remainder:                                                                                        \
+        if (nextEmit < n) {                                                                                \
+            if (d + n - nextEmit > dstLimit) goto done;                                                    \
+            d += mlzo_emit_literal(dst + d, src + nextEmit, n - nextEmit);                                 \
+        }                                                                                                  \
+        ret = (size_t)d;                                                                                   \
+    done:                                                                                                  \
+        free(lTable); free(sTable);                                                                        \
+        return ret;                                                                                        \
+    }
+
+DEFINE_L2(l2_big, 1, 17, 14, uint32_t, hash7)
+DEFINE_L2(l2_64k, 0, 15, 12, uint16_t, hash6)
+
+/* encodeBlockBetter, asm_none.go:68-76 */
+size_t mlzo_encode_block_l2(uint8_t* dst, const uint8_t* src, size_t n) {
+    if (n < MIN_NON_LITERAL_BLOCK_SIZE) return 0;
+    if (n <= (64 << 10)) return l2_64k(dst, src, (long)n);
+    return l2_big(dst, src, (long)n);
+}
+
+/* encodeUncompressed, encode.go:223-228 */
+static long encode_uncompressed(uint8_t* dst, const uint8_t* src, size_t n) {
+    if (n == 0) { dst[0] = 0; return 1; }
+    dst[0] = 0; dst[1] = 0; memcpy(dst + 2, src, n);
+    return (long)n + 2;
+}
+
+/* Encode, encode.go:74-139.  Levels: 0 uncompressed, 1 fastest, 2 balanced.
+ * (LevelSuperFast -1 and LevelSmallest 3 are not restated: SURVEY.md section 2 rows 6-7.) */
+long mlzo_encode(uint8_t* dst, size_t dcap, const uint8_t* src, size_t n, int level) {
+    long maxlen = mlzo_max_encoded_len(n);
+    if (maxlen < 0) return -MLZO_ERR_TOO_LARGE;
+    if (dcap < (size_t)maxlen) return -MLZO_ERR_DST_TOO_SMALL;
+    if (n < MIN_NON_LITERAL_BLOCK_SIZE) return encode_uncompressed(dst, src, n);
+    dst[0] = 0;
+    size_t d = 1 + put_uvarint(dst + 1, n);
+    size_t m;
+    switch (level) {
+    case 0: return encode_uncompressed(dst, src, n);
+    case 1: m = mlzo_encode_block_l1(dst + d, src, n); break;
+    case 2: m = mlzo_encode_block_l2(dst + d, src, n); break;
+    default: return -MLZO_ERR_INVALID_LEVEL;
+    }
+    if (m > 0) return (long)(d + m);
+    return encode_uncompressed(dst, src, n);
+}
+
+/* ======================================================================================
+ * Stream framing
+ * ====================================================================================== */
+
+/* CRC32C (Castagnoli, reflected poly 0x82f63b78), table-driven; then the Snappy-framing mask
+ * of minlz.go:137-140. */
+static uint32_t crc_tab[8][256];
+static pthread_once_t crc_once = PTHREAD_ONCE_INIT;
+static void crc_init(void) {
+    for (uint32_t i = 0; i < 256; i++) {
+        uint32_t c = i;
+        for (int k = 0; k < 8; k++) c = (c & 1) ? (c >> 1) ^ 0x82f63b78u : c >> 1;
+        crc_tab[0][i] = c;
+    }
+    for (uint32_t i = 0; i < 256; i++)
+        for (int t = 1; t < 8; t++) crc_tab[t][i] = (crc_tab[t - 1][i] >> 8) ^ crc_tab[0][crc_tab[t - 1][i] & 0xff];
+}
+uint32_t mlzo_crc(const uint8_t* b, size_t n) {
+    pthread_once(&crc_once, crc_init);
+    uint32_t c = 0xffffffffu;
+    while (n >= 8) {
+        uint64_t v = ld64(b, 0) ^ c;
+        c = crc_tab[7][v & 0xff] ^ crc_tab[6][(v >> 8) & 0xff] ^ crc_tab[5][(v >> 16) & 0xff] ^ crc_tab[4][(v >> 24) & 0xff] ^
+            crc_tab[3][(v >> 32) & 0xff] ^ crc_tab[2][(v >> 40) & 0xff] ^ crc_tab[1][(v >> 48) & 0xff] ^ crc_tab[0][v >> 56];
+        b += 8; n -= 8;
+    }
+    while (n--) c = crc_tab[0][(c ^ *b++) & 0xff] ^ (c >> 8);
+    c = ~c;
+    return (c >> 15 | c << 17) + 0xa282ead8u;
+}
+
+static const uint8_t MAGIC_CHUNK[9] = {0xff, 0x06, 0x00, 0x00, 'M', 'i', 'n', 'L', 'z'}; /* minlz.go:95-100 */
+
+size_t mlzo_stream_bound(size_t n, size_t block_size) {
+    size_t blocks = (n + block_size - 1) / block_size;
+    return 10 + n + blocks * (8 + 5 + 2) + 4 + 10;
+}
+
+static unsigned bits_len(size_t v) { unsigned n = 0; while (v) { n++; v >>= 1; } return n; }
+
+/* Writer sync path: makeHeader (writer.go:1553-1556), per block (writer.go:876-959), EOF chunk
+ * (writer.go:1063-1074).  No index, no padding. */
+long mlzo_stream_encode(uint8_t* dst, size_t dcap, const uint8_t* src, size_t n, int level, size_t block_size) {
+    if (block_size > MLZO_MAX_BLOCK_SIZE || block_size < (4 << 10)) return -MLZO_ERR_TOO_LARGE; /* writer.go:1238-1246 */
+    if (dcap < mlzo_stream_bound(n, block_size)) return -MLZO_ERR_DST_TOO_SMALL;
+    size_t o = 0;
+    if (n > 0) { /* header is written lazily with the first block */
+        memcpy(dst, MAGIC_CHUNK, 9); dst[9] = (uint8_t)(bits_len(block_size - 1) - 10); o = 10;
+    }
+    size_t pos = 0;
+    while (pos < n) {
+        size_t bl = n - pos < block_size ? n - pos : block_size;
+        const uint8_t* u = src + pos;
+        uint32_t checksum = mlzo_crc(u, bl);
+        uint8_t* ob = dst + o;
+        size_t vn = put_uvarint(ob + 8, bl);
+        size_t n2 = 0;
+        switch (level) { /* (*Writer).encodeBlock, writer.go:565-602 */
+        case 0: n2 = 0; break;
+        case 1: n2 = mlzo_encode_block_l1(ob + 8 + vn, u, bl); break;
+        case 2: n2 = mlzo_encode_block_l2(ob + 8 + vn, u, bl); break;
+        default: return -MLZO_ERR_INVALID_LEVEL;
+        }
+        size_t chunk_len; uint8_t type;
+        if (n2 > 0) { type = 0x02; chunk_len = 4 + vn + n2; }
+        else { type = 0x01; chunk_len = 4 + bl; memcpy(ob + 8, u, bl); }
+        ob[0] = type; ob[1] = (uint8_t)chunk_len; ob[2] = (uint8_t)(chunk_len >> 8); ob[3] = (uint8_t)(chunk_len >> 16);
+        st32(ob, 4, checksum);
+        o += 4 + chunk_len;
+        pos += bl;
+    }
+    /* EOF chunk: 0x20, len24 = varint length, uvarint(total uncompressed) */
+    uint8_t* e = dst + o;
+    int vn = put_uvarint(e + 4, n);
+    e[0] = 0x20; e[1] = (uint8_t)vn; e[2] = 0; e[3] = 0;
+    o += 4 + vn;
+    return (long)o;
+}
+
+/* Reader.Read, reader.go:248-543, for MinLZ streams (no Snappy/S2 fallback). */
+int mlzo_stream_decode(const uint8_t* src, size_t slen, uint8_t* dst, size_t dcap, size_t* dlen) {
+    size_t p = 0, o = 0, max_block = MLZO_MAX_BLOCK_SIZE, stream_out = 0;
+    int read_header = 0, want_eof = 0;
+    *dlen = 0;
+    for (;;) {
+        if (p == slen) { *dlen = o; return want_eof ? MLZO_ERR_CORRUPT : MLZO_OK; } /* io.ErrUnexpectedEOF when an EOF chunk is owed */
+        if (slen - p < 4) return MLZO_ERR_CORRUPT;
+        uint8_t type = src[p];
+        size_t clen = (size_t)src[p + 1] | (size_t)src[p + 2] << 8 | (size_t)src[p + 3] << 16;
+        p += 4;
+        if (!read_header) {
+            if (type == 0xff) read_header = 1;
+            else if (type <= 0x3f && type != 0x20) return MLZO_ERR_CORRUPT;
+        }
+        switch (type) {
+        case 0x02: case 0x03: { /* reader.go:286-353 */
+            if (clen < 4) return MLZO_ERR_CORRUPT;
+            if (clen > (size_t)mlzo_max_encoded_len(max_block) + 4) return MLZO_ERR_CORRUPT; /* ensureBufferSize, reader.go:163-167 */
+            if (slen - p < clen) return MLZO_ERR_CORRUPT;
+            uint32_t checksum = ld32(src, p);
+            const uint8_t* buf = src + p + 4; size_t bl = clen - 4;
+            size_t nn, hl; int e = decoded_len_raw(buf, bl, &nn, &hl);
+            if (e) return e;
+            if (nn > max_block) return MLZO_ERR_TOO_LARGE;
+            buf += hl; bl -= hl;
+            if (nn == 0 || nn < bl) return MLZO_ERR_CORRUPT;
+            if (nn > dcap - o) return MLZO_ERR_DST_TOO_SMALL;
+            if (mlzo_decode_body(dst + o, nn, buf, bl) != 0) return MLZO_ERR_CORRUPT;
+            uint32_t got = type == 0x03 ? mlzo_crc(buf, bl) : mlzo_crc(dst + o, nn);
+            if (got != checksum) return MLZO_ERR_CRC;
+            o += nn; stream_out += nn; p += clen;
+            continue;
+        }
+        case 0x00: return MLZO_ERR_UNSUPPORTED; /* legacy S2/Snappy chunk: fallback out of scope */
+        case 0x01: { /* reader.go:411-464 */
+            if (clen < 4) return MLZO_ERR_CORRUPT;
+            if (clen > (size_t)mlzo_max_encoded_len(max_block) + 4) return MLZO_ERR_CORRUPT; /* ensureBufferSize, reader.go:163-167 */
+            if (slen - p < 4) return MLZO_ERR_CORRUPT;
+            uint32_t checksum = ld32(src, p);
+            size_t nn = clen - 4;
+            if (nn > max_block) return MLZO_ERR_TOO_LARGE;
+            if (slen - p - 4 < nn) return MLZO_ERR_CORRUPT;
+            if (nn > dcap - o) return MLZO_ERR_DST_TOO_SMALL;
+            memcpy(dst + o, src + p + 4, nn);
+            if (mlzo_crc(dst + o, nn) != checksum) return MLZO_ERR_CRC;
+            o += nn; stream_out += nn; p += clen;
+            continue;
+        }
+        case 0x20: { /* EOF, reader.go:465-499 */
+            if (clen > 10) return MLZO_ERR_CORRUPT;
+            if (clen != 0) {
+                if (slen - p < clen) return MLZO_ERR_CORRUPT;
+                uint64_t want; int vn = uvarint(src + p, clen, &want);
+                if (vn != (int)clen) return MLZO_ERR_CORRUPT;
+                if (want != stream_out) return MLZO_ERR_CORRUPT;
+                p += clen;
+            }
+            want_eof = 0; read_header = 0;
+            continue;
+        }
+        case 0xff: { /* stream identifier, reader.go:500-527 + minLzHeader :994-1027 */
+            if (clen != 6) return MLZO_ERR_CORRUPT;
+            if (slen - p < 6) return MLZO_ERR_CORRUPT;
+            if (memcmp(src + p, "MinLz", 5) != 0) return MLZO_ERR_UNSUPPORTED;
+            uint8_t b = src[p + 5];
+            if (b & (3 << 6)) return MLZO_ERR_CORRUPT;
+            unsigned lg = (b & 15) + 10;
+            if (lg > 23) return MLZO_ERR_CORRUPT;
+            max_block = (size_t)1 << lg;
+            stream_out = 0; want_eof = 1;
+            p += 6;
+            continue;
+        }
+        default: break;
+        }
+        if (type <= 0x3f) return MLZO_ERR_UNSUPPORTED; /* reserved unskippable, reader.go:530-536 */
+        if (slen - p < clen) return MLZO_ERR_CORRUPT;   /* skippable chunk */
+        p += clen;
+    }
+}
+
+/* ======================================================================================
+ * Multi-threaded block bench (cpu_baseline leg).  One block per thread at a time, as
+ * BenchmarkEncodeBlockParallel (benchmarks_test.go:101-107) / mz -bench (cmd/mz/compress.go:647-803).
+ * ====================================================================================== */
+typedef struct {
+    const uint8_t* src; size_t n, block; int level, reps, decode;
+    uint8_t** enc; size_t* enc_len; /* per block */
+    int tid, threads; size_t nblocks;
+} bench_arg;
+
+static void* bench_worker(void* p) {
+    bench_arg* a = (bench_arg*)p;
+    uint8_t* tmp = (uint8_t*)malloc(a->block + 16);
+    for (int r = 0; r < a->reps; r++) {
+        for (size_t b = (size_t)a->tid; b < a->nblocks; b += (size_t)a->threads) {
+            size_t off = b * a->block, bl = a->n - off < a->block ? a->n - off : a->block;
+            if (!a->decode) {
+                long m = mlzo_encode(a->enc[b], bl + 16, a->src + off, bl, a->level);
+                a->enc_len[b] = m > 0 ? (size_t)m : 0;
+            } else {
+                size_t dl;
+                mlzo_decode(a->enc[b], a->enc_len[b], tmp, a->block + 16, &dl);
+            }
+        }
+    }
+    free(tmp);
+    return NULL;
+}
+
+static double now_s(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
+
+static double bench_run(const uint8_t* src, size_t n, size_t block, int level, int threads, int reps, int decode,
+                        uint8_t** enc, size_t* enc_len, size_t nblocks) {
+    pthread_t* th = (pthread_t*)malloc(sizeof(pthread_t) * threads);
+    bench_arg* args = (bench_arg*)malloc(sizeof(bench_arg) * threads);
+    double t0 = now_s();
+    for (int t = 0; t < threads; t++) {
+        args[t] = (bench_arg){src, n, block, level, reps, decode, enc, enc_len, t, threads, nblocks};
+        pthread_create(&th[t], NULL, bench_worker, &args[t]);
+    }
+    for (int t = 0; t < threads; t++) pthread_join(th[t], NULL);
+    double dt = now_s() - t0;
+    free(th); free(args);
+    return dt;
+}
+
+double mlzo_bench_encode(const uint8_t* src, size_t n, size_t block, int level, int threads, int reps, size_t* total_out) {
+    size_t nblocks = (n + block - 1) / block;
+    uint8_t** enc = (uint8_t**)malloc(sizeof(uint8_t*) * nblocks);
+    size_t* enc_len = (size_t*)calloc(nblocks, sizeof(size_t));
+    for (size_t b = 0; b < nblocks; b++) enc[b] = (uint8_t*)malloc(block + 16);
+    double dt = bench_run(src, n, block, level, threads, reps, 0, enc, enc_len, nblocks);
+    size_t tot = 0;
+    for (size_t b = 0; b < nblocks; b++) { tot += enc_len[b]; free(enc[b]); }
+    if (total_out) *total_out = tot;
+    free(enc); free(enc_len);
+    return dt;
+}
+
+double mlzo_bench_decode(const uint8_t* src, size_t n, size_t block, int level, int threads, int reps) {
+    size_t nblocks = (n + block - 1) / block;
+    uint8_t** enc = (uint8_t**)malloc(sizeof(uint8_t*) * nblocks);
+    size_t* enc_len = (size_t*)calloc(nblocks, sizeof(size_t));
+    for (size_t b = 0; b < nblocks; b++) enc[b] = (uint8_t*)malloc(block + 16);
+    bench_run(src, n, block, level, threads, 1, 0, enc, enc_len, nblocks); /* untimed: produce the blocks */
+    double dt = bench_run(src, n, block, level, threads, reps, 1, enc, enc_len, nblocks);
+    for (size_t b = 0; b < nblocks; b++) free(enc[b]);
+    free(enc); free(enc_len);
+    return dt;
+}

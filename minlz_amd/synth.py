@@ -177,9 +177,10 @@ def pattern(name, size):
             d[p + 4] = p % 256
             d[p + 5] = (p + 1) % 256
         return d
-    if name == "half":       # minlz_test.go:780-797: half noise, half ramp
+    if name == "half":       # minlz_test.go:776-797: half noise, half runs of uint8(i >> 8)
         d = np.random.default_rng(1).integers(0, 256, size=size, dtype=np.uint8)
-        d[size // 2:] = (i[size // 2:] % 256).astype(np.uint8)
+        h = size - size // 2
+        d[size // 2:] = (np.arange(h, dtype=np.int64) >> 8).astype(np.uint8)
         return d
     raise KeyError(name)
 

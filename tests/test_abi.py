@@ -1,0 +1,77 @@
+"""The C-ABI shared library loads and exports every symbol include/minlz_hip.h declares; the
+host-only entry points behave like the reference's size helpers.  No GPU compute here."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from minlz_amd import _build, _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    _build.build()
+    return _lib.lib()
+
+
+def header_symbols():
+    txt = open(os.path.join(ROOT, "include", "minlz_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(mlz_[a-z_0-9]+)\s*\(", txt)))
+
+
+def test_header_symbols_exported(lib):
+    syms = header_symbols()
+    assert len(syms) >= 18
+    for s in syms:
+        assert hasattr(lib, s), "libminlz_hip.so does not export %s" % s
+    assert sorted(_lib.SYMBOLS) == syms
+
+
+def test_max_encoded_len(lib):
+    # TestMaxEncodedLen, minlz_test.go:42-69
+    assert lib.mlz_max_encoded_len(0) == 1
+    assert lib.mlz_max_encoded_len(32) == 34
+    assert lib.mlz_max_encoded_len(8 << 20) == (8 << 20) + 2
+    assert lib.mlz_max_encoded_len((8 << 20) + 1) == -1
+    assert lib.mlz_max_encoded_len(0xffffffff) == -1
+    for n in (1, 15, 16, 4095, 4096, 65536, 1 << 20):
+        assert lib.mlz_max_encoded_len(n) == n + 2
+
+
+def _dl(lib, b):
+    a = np.frombuffer(b, dtype=np.uint8)
+    return lib.mlz_decoded_len(a.ctypes.data if a.size else None, a.size)
+
+
+def test_decoded_len_matches_reference_rules(lib, twain_mzb):
+    assert _dl(lib, twain_mzb) == 14168
+    assert _dl(lib, b"\x00") == 0
+    assert _dl(lib, b"") == -1                       # ErrCorrupt
+    assert _dl(lib, b"\x00\x05") == -1               # header only
+    assert _dl(lib, b"\x00\x00abc") == 3             # v == 0: rest are literals
+    assert _dl(lib, b"\x00\x02\x08abc") == -1        # decoded smaller than body
+    assert _dl(lib, b"\x00\x81\x80\x80\x04\x00") == -2  # > 8 MiB: ErrTooLarge
+    assert _dl(lib, b"\x00\xff\xff\xff\xff\xff\xff\xff\xff\xff\x7f") == -1  # varint overflow
+    assert _dl(lib, b"\x03abc") == 3                 # Snappy block: size still reported (decode.go:132-136)
+
+
+def test_version_and_timer_names(lib):
+    assert lib.mlz_version() >= 1
+    names = [lib.mlz_timer_name(i).decode() for i in range(9)]
+    assert "enc_tiles" in names and "dec_exec" in names
+
+
+def test_init_without_gpu_fails_loudly(lib):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    h = C.c_void_p()
+    assert lib.mlz_init(0, C.byref(h)) < 0 and not h.value
+    import minlz_amd as mz
+    with pytest.raises(mz.ErrHIP):
+        mz.Context(0)

@@ -1,0 +1,169 @@
+"""Decode parity (bit-exact) of the HIP decoder against the oracle / golden fixtures, through the C ABI."""
+import numpy as np
+import pytest
+
+import minlz_amd as mz
+import oracle as O
+from minlz_amd import synth
+from tests.util import load_zip
+
+pytestmark = pytest.mark.gpu
+
+
+def gpu_decode_result(blob, ctx):
+    try:
+        return ("ok", mz.Decode(blob, ctx, guard=64))
+    except mz.MinLZError as e:
+        return ("err", e.code)
+
+
+def oracle_decode_result(blob):
+    try:
+        return ("ok", O.decode(blob))
+    except O.OracleError as e:
+        return ("err", e.code)
+
+
+def test_golden_mzb(ctx, twain, twain_mzb):
+    # minlz_test.go:626-660
+    assert mz.Decode(twain_mzb, ctx, guard=64) == twain
+    ctx.set_option(mz.OPT_DECODE_ALGO, 1)
+    try:
+        assert mz.Decode(twain_mzb, ctx, guard=64) == twain
+    finally:
+        ctx.set_option(mz.OPT_DECODE_ALGO, 0)
+
+
+def test_header_and_error_kats(ctx):
+    assert mz.Decode(b"\x00", ctx) == b""
+    assert mz.Decode(b"\x00\x00abc", ctx) == b"abc"
+    for bad, exc in ((b"", mz.ErrCorrupt), (b"\x00\x05", mz.ErrCorrupt), (b"\x00\x02\x08abc", mz.ErrCorrupt),
+                     (b"\x00\x81\x80\x80\x04\x00", mz.ErrTooLarge), (b"\x03\x08abc", mz.ErrUnsupported),
+                     (b"\x00\xff\xff\xff\xff\xff\xff\xff\xff\xff\x7f", mz.ErrCorrupt)):
+        with pytest.raises(exc):
+            mz.Decode(bad, ctx)
+
+
+def test_negative_corpus_same_verdict_as_oracle(ctx):
+    # fuzz/block-corpus-dec.zip: corrupt MinLZ blocks, streams, Snappy blocks. Same verdict and
+    # (when valid) same bytes as the oracle; never writes past dst (guard bytes).
+    n = 0
+    for name in ("block-corpus-dec.zip", "dec-block-regressions.zip"):
+        for label, blob in load_zip(name):
+            want = oracle_decode_result(blob)
+            got = gpu_decode_result(blob, ctx)
+            assert got == want, (label, got[0], want[0], got[1] if got[0] == "err" else None, want[1] if want[0] == "err" else None)
+            n += 1
+    assert n > 500
+
+
+@pytest.mark.parametrize("level", [1, 2])
+def test_oracle_encoded_regressions(ctx, level):
+    # reference-algorithm streams (arbitrary cross-tile references) must decode bit-exact
+    for label, blob in load_zip("enc_regressions.zip"):
+        enc = O.encode(blob, level)
+        assert mz.Decode(enc, ctx, guard=64) == blob, label
+
+
+def test_oracle_encoded_corpus_sample(ctx):
+    items = load_zip("block-corpus-enc.zip")
+    for label, blob in items[::12]:
+        assert mz.Decode(O.encode(blob, 1), ctx) == blob, label
+        assert mz.Decode(O.encode(blob, 2), ctx) == blob, label
+
+
+@pytest.mark.parametrize("name", synth.PATTERNS)
+def test_patterns(ctx, name):
+    for size in (17, 100, 4096, 65535, 65536, 65549, 70000, 300000):
+        d = synth.pattern(name, size)
+        for level in (0, 1, 2):
+            assert mz.Decode(O.encode(d, level), ctx, guard=64) == d.tobytes(), (name, size, level)
+
+
+def test_margin_sizes(ctx):
+    # TestSrcMarginBoundary shapes, decode_asm_test.go:352-410
+    for size in list(range(16, 40)) + [50, 60, 70, 80]:
+        for pat in (b"a", b"ab", b"abcd"):
+            d = (pat * (size // len(pat) + 1))[:size]
+            for level in (1, 2):
+                assert mz.Decode(O.encode(d, level), ctx, guard=64) == d
+
+
+def test_large_offsets_and_short_repeats(ctx):
+    for min_off in (65536, 65600, 200000, 1 << 20, (2 << 20) + 65535):
+        d = synth.large_offset(min_off + 5000, min_off)
+        for level in (1, 2):
+            assert mz.Decode(O.encode(d, level), ctx) == d.tobytes()
+    for off, ln in ((1, 4), (2, 4), (2, 10), (3, 9), (4, 16)):
+        d = synth.short_repeat(off, ln)
+        assert mz.Decode(O.encode(d, 1), ctx) == d.tobytes()
+
+
+def test_long_tokens_spanning_tiles(ctx):
+    # one literal / one copy covering many 64 KiB tiles, and overlapping copies with tiny periods
+    z = np.zeros(8 << 20, dtype=np.uint8)
+    assert mz.Decode(O.encode(z, 1), ctx) == z.tobytes()
+    for period in (1, 2, 3, 5, 63, 64, 65, 1000):
+        d = np.tile(np.arange(period, dtype=np.uint8) + 7, (1 << 20) // period + 1)[:1 << 20]
+        assert mz.Decode(O.encode(d, 1), ctx) == d.tobytes(), period
+    # hand-built: literal of 200000 bytes, then copy3 far back, then repeat
+    lit = synth.random_bytes(200000, 3).tobytes()
+    tok = O.emit_literal(lit) + O.emit_copy(150000, 300000) + O.emit_repeat(70000)
+    want = bytearray(lit)
+    for _ in range(370000):
+        want.append(want[len(want) - 150000])
+    code, got = mz.decode_block(tok, len(want), ctx)
+    assert code == 0 and got == bytes(want)
+    assert O.decode_body(tok, len(want)) == (0, bytes(want))
+
+
+def test_decode_block_corrupt_verdicts(ctx):
+    # minLZDecode contract (decode.go:178): 0 ok / 1 corrupt, same as the oracle, on mutated streams
+    d = synth.text_like(200000, 9)
+    body = O.encode_block(d, 1)
+    rng = np.random.default_rng(5)
+    assert mz.decode_block(body, d.size, ctx) == (0, d.tobytes())
+    for trial in range(40):
+        b = bytearray(body)
+        kind = trial % 4
+        if kind == 0:
+            b = b[:int(rng.integers(1, len(b)))]             # truncated
+        elif kind == 1:
+            b[int(rng.integers(0, len(b)))] ^= 1 << int(rng.integers(0, 8))  # bit flip
+        elif kind == 2:
+            b += bytes(rng.integers(0, 256, size=3, dtype=np.uint8))       # trailing garbage
+        else:
+            p = int(rng.integers(0, len(b) - 8)); b[p:p + 4] = b"\xff\xff\xff\xff"
+        ocode, oout = O.decode_body(bytes(b), d.size)
+        gcode, gout = mz.decode_block(bytes(b), d.size, ctx)
+        assert gcode == ocode, trial
+        if ocode == 0:
+            assert gout == oout
+    # wrong destination length
+    assert mz.decode_block(body, d.size - 1, ctx)[0] == 1
+    assert mz.decode_block(body, d.size + 1, ctx)[0] == 1
+
+
+def test_full_size_blocks(ctx):
+    for gen in (lambda: synth.text_like(8 << 20, 11), lambda: synth.json_like(8 << 20), lambda: synth.random_bytes(8 << 20)):
+        d = gen()
+        for level in (1, 2):
+            assert mz.Decode(O.encode(d, level), ctx) == d.tobytes()
+
+
+def test_serial_and_parallel_agree(ctx):
+    d = synth.text_like(1 << 20, 13)
+    enc = O.encode(d, 2)
+    a = mz.Decode(enc, ctx)
+    ctx.set_option(mz.OPT_DECODE_ALGO, 1)
+    try:
+        b = mz.Decode(enc, ctx)
+    finally:
+        ctx.set_option(mz.OPT_DECODE_ALGO, 0)
+    assert a == b == d.tobytes()
+
+
+def test_decode_batch(ctx):
+    blocks = [synth.text_like(300000, s).tobytes() for s in range(5)] + [b"", b"abc", synth.random_bytes(70000).tobytes()]
+    encs = [O.encode(b, 1) for b in blocks]
+    assert mz.decode_batch(encs, ctx) == blocks

@@ -1,0 +1,132 @@
+"""Encode parity of the HIP encoder: output may differ byte-wise from the reference, but the
+oracle decoder (pinned on the reference's golden vectors) must reproduce the input bit-exact,
+the block rules of encode.go:74-139 must hold, and the size must stay within the stated
+tolerance of the oracle's restatement of the reference L1 encoder."""
+import numpy as np
+import pytest
+
+import minlz_amd as mz
+import oracle as O
+from minlz_amd import synth
+from tests.util import load_zip
+
+pytestmark = pytest.mark.gpu
+
+# Stated ratio tolerance (DESIGN.md "Ratio"): C_gpu <= RATIO_TOL * C_oracle_L1 on text-like and
+# JSON-like 8 MiB blocks.
+RATIO_TOL = 1.15
+
+
+def roundtrip(d, ctx, level=1):
+    d = np.ascontiguousarray(np.frombuffer(d, dtype=np.uint8) if not isinstance(d, np.ndarray) else d)
+    enc = mz.Encode(d, level, ctx)
+    assert len(enc) <= mz.MaxEncodedLen(d.size)
+    assert O.decode(enc, guard=64) == d.tobytes()
+    return enc
+
+
+def test_block_container_rules(ctx):
+    # encode.go:83-90,137-138, encodeUncompressed :223-228
+    assert mz.Encode(b"", 1, ctx) == b"\x00"
+    assert mz.Encode(b"abc", 1, ctx) == b"\x00\x00abc"
+    small = bytes(range(15))
+    assert mz.Encode(small, 1, ctx) == b"\x00\x00" + small
+    r = synth.random_bytes(100000).tobytes()
+    assert mz.Encode(r, 1, ctx) == b"\x00\x00" + r           # incompressible -> stored
+    assert mz.Encode(r, 0, ctx) == b"\x00\x00" + r           # LevelUncompressed
+    z = mz.Encode(bytes(100000), 1, ctx)
+    assert z[:1] == b"\x00" and z[1:4] == b"\xa0\x8d\x06"     # 00 + uvarint(100000)
+    with pytest.raises(mz.ErrTooLarge):
+        mz.Encode(np.zeros((8 << 20) + 1, dtype=np.uint8), 1, ctx)
+    with pytest.raises(mz.ErrInvalidLevel):
+        mz.Encode(bytes(100), 7, ctx)
+
+
+@pytest.mark.parametrize("far", [0, 1])
+def test_enc_regressions_roundtrip(ctx, far):
+    ctx.set_option(mz.OPT_ENCODE_FAR, far)
+    try:
+        for label, blob in load_zip("enc_regressions.zip"):
+            roundtrip(blob, ctx)
+    finally:
+        ctx.set_option(mz.OPT_ENCODE_FAR, 1)
+
+
+def test_corpus_roundtrip(ctx):
+    for label, blob in load_zip("block-corpus-enc.zip")[::5]:
+        roundtrip(blob, ctx)
+
+
+@pytest.mark.parametrize("name", synth.PATTERNS)
+def test_patterns(ctx, name):
+    for size in (16, 17, 100, 4096, 65535, 65536, 65537, 65549, 70000, 131072, 300000):
+        roundtrip(synth.pattern(name, size), ctx)
+
+
+def test_sizes_sweep(ctx):
+    d = synth.text_like(200000, 21)
+    for size in list(range(0, 70)) + [255, 256, 1000, 65528, 65529, 65535, 65536, 65537, 65543, 65544, 65545, 131071, 131072, 131073, 199999]:
+        roundtrip(d[:size], ctx)
+
+
+def test_large_offsets(ctx):
+    for min_off in (65536, 65600, 200000, 1 << 20, (2 << 20) + 65535, 3 << 20):
+        roundtrip(synth.large_offset(min_off + 5000, min_off), ctx)
+
+
+def test_ratio_half_noise(ctx):
+    # TestEncodeNoiseThenRepeats, minlz_test.go:776-797
+    for n in (256 * 1024, 2048 * 1024):
+        enc = roundtrip(synth.pattern("half", n), ctx)
+        assert len(enc) < n * 3 // 4
+
+
+def test_huge_zeros(ctx):
+    # TestEncodeHuge, encode_test.go:26-50
+    enc = roundtrip(np.zeros(8 << 20, dtype=np.uint8), ctx)
+    assert len(enc) < 4096
+
+
+@pytest.mark.parametrize("kind", ["text", "json"])
+def test_ratio_within_tolerance_of_reference_l1(ctx, kind):
+    d = synth.text_like(8 << 20, 1) if kind == "text" else synth.json_like(8 << 20)
+    enc = roundtrip(d, ctx)
+    ref = O.encode(d, 1)
+    assert len(enc) <= RATIO_TOL * len(ref), (len(enc), len(ref))
+
+
+def test_encode_block_contract(ctx):
+    # WriterCustomEncoder / encodeBlock contract: tokens only; 0 = incompressible
+    d = synth.text_like(300000, 2)
+    body = mz.encode_block(d, 1, ctx)
+    assert 0 < len(body) < d.size
+    assert O.decode_body(body, d.size) == (0, d.tobytes())
+    assert mz.encode_block(synth.random_bytes(100000), 1, ctx) == b""
+    assert mz.encode_block(b"0123456789", 1, ctx) == b""
+
+
+def test_try_encode(ctx):
+    assert mz.TryEncode(synth.random_bytes(50000), 1, ctx) is None
+    d = synth.text_like(50000, 3)
+    e = mz.TryEncode(d, 1, ctx)
+    assert e is not None and O.decode(e) == d.tobytes()
+
+
+def test_deterministic(ctx):
+    d = synth.text_like(2 << 20, 4)
+    assert mz.Encode(d, 1, ctx) == mz.Encode(d, 1, ctx)
+
+
+def test_batch_and_gpu_roundtrip(ctx):
+    blocks = [synth.text_like(8 << 20, 31).tobytes(), synth.json_like(3 << 20).tobytes(), b"", b"x" * 20,
+              synth.random_bytes(1 << 20).tobytes(), synth.pattern("off2", 70000).tobytes()]
+    encs = mz.encode_batch(blocks, 1, ctx)
+    for b, e in zip(blocks, encs):
+        assert O.decode(e) == b
+    assert mz.decode_batch(encs, ctx) == blocks
+
+
+def test_level_balanced_roundtrip(ctx):
+    d = synth.json_like(2 << 20)
+    enc = roundtrip(d, ctx, level=2)
+    assert len(enc) < d.size // 2

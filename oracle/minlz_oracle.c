@@ -761,23 +761,26 @@ int mlzo_stream_decode(const uint8_t* src, size_t slen, uint8_t* dst, size_t dca
  * ====================================================================================== */
 typedef struct {
     const uint8_t* src; size_t n, block; int level, reps, decode;
-    uint8_t** enc; size_t* enc_len; /* per block */
+    uint8_t** enc; size_t* enc_len; /* per block (decode input) */
     int tid, threads; size_t nblocks;
+    size_t out_bytes; /* per thread: compressed bytes produced (encode) */
 } bench_arg;
 
+/* Work items are (rep, block) pairs dealt round-robin to the threads, so every thread is busy
+ * even when there are fewer blocks than cores; each thread owns its output buffer. */
 static void* bench_worker(void* p) {
     bench_arg* a = (bench_arg*)p;
     uint8_t* tmp = (uint8_t*)malloc(a->block + 16);
-    for (int r = 0; r < a->reps; r++) {
-        for (size_t b = (size_t)a->tid; b < a->nblocks; b += (size_t)a->threads) {
-            size_t off = b * a->block, bl = a->n - off < a->block ? a->n - off : a->block;
-            if (!a->decode) {
-                long m = mlzo_encode(a->enc[b], bl + 16, a->src + off, bl, a->level);
-                a->enc_len[b] = m > 0 ? (size_t)m : 0;
-            } else {
-                size_t dl;
-                mlzo_decode(a->enc[b], a->enc_len[b], tmp, a->block + 16, &dl);
-            }
+    size_t items = (size_t)a->reps * a->nblocks;
+    for (size_t it = (size_t)a->tid; it < items; it += (size_t)a->threads) {
+        size_t b = it % a->nblocks;
+        size_t off = b * a->block, bl = a->n - off < a->block ? a->n - off : a->block;
+        if (!a->decode) {
+            long m = mlzo_encode(tmp, bl + 16, a->src + off, bl, a->level);
+            if (m > 0) a->out_bytes += (size_t)m;
+        } else {
+            size_t dl;
+            mlzo_decode(a->enc[b], a->enc_len[b], tmp, a->block + 16, &dl);
         }
     }
     free(tmp);
@@ -787,30 +790,27 @@ static void* bench_worker(void* p) {
 static double now_s(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
 
 static double bench_run(const uint8_t* src, size_t n, size_t block, int level, int threads, int reps, int decode,
-                        uint8_t** enc, size_t* enc_len, size_t nblocks) {
+                        uint8_t** enc, size_t* enc_len, size_t nblocks, size_t* out_bytes) {
     pthread_t* th = (pthread_t*)malloc(sizeof(pthread_t) * threads);
     bench_arg* args = (bench_arg*)malloc(sizeof(bench_arg) * threads);
     double t0 = now_s();
     for (int t = 0; t < threads; t++) {
-        args[t] = (bench_arg){src, n, block, level, reps, decode, enc, enc_len, t, threads, nblocks};
+        args[t] = (bench_arg){src, n, block, level, reps, decode, enc, enc_len, t, threads, nblocks, 0};
         pthread_create(&th[t], NULL, bench_worker, &args[t]);
     }
-    for (int t = 0; t < threads; t++) pthread_join(th[t], NULL);
+    size_t tot = 0;
+    for (int t = 0; t < threads; t++) { pthread_join(th[t], NULL); tot += args[t].out_bytes; }
     double dt = now_s() - t0;
+    if (out_bytes) *out_bytes = tot;
     free(th); free(args);
     return dt;
 }
 
+/* reps passes over the blocks of src; *total_out = compressed bytes of ONE pass. */
 double mlzo_bench_encode(const uint8_t* src, size_t n, size_t block, int level, int threads, int reps, size_t* total_out) {
-    size_t nblocks = (n + block - 1) / block;
-    uint8_t** enc = (uint8_t**)malloc(sizeof(uint8_t*) * nblocks);
-    size_t* enc_len = (size_t*)calloc(nblocks, sizeof(size_t));
-    for (size_t b = 0; b < nblocks; b++) enc[b] = (uint8_t*)malloc(block + 16);
-    double dt = bench_run(src, n, block, level, threads, reps, 0, enc, enc_len, nblocks);
-    size_t tot = 0;
-    for (size_t b = 0; b < nblocks; b++) { tot += enc_len[b]; free(enc[b]); }
-    if (total_out) *total_out = tot;
-    free(enc); free(enc_len);
+    size_t nblocks = (n + block - 1) / block, tot = 0;
+    double dt = bench_run(src, n, block, level, threads, reps, 0, NULL, NULL, nblocks, &tot);
+    if (total_out) *total_out = reps ? tot / (size_t)reps : 0;
     return dt;
 }
 
@@ -818,9 +818,13 @@ double mlzo_bench_decode(const uint8_t* src, size_t n, size_t block, int level, 
     size_t nblocks = (n + block - 1) / block;
     uint8_t** enc = (uint8_t**)malloc(sizeof(uint8_t*) * nblocks);
     size_t* enc_len = (size_t*)calloc(nblocks, sizeof(size_t));
-    for (size_t b = 0; b < nblocks; b++) enc[b] = (uint8_t*)malloc(block + 16);
-    bench_run(src, n, block, level, threads, 1, 0, enc, enc_len, nblocks); /* untimed: produce the blocks */
-    double dt = bench_run(src, n, block, level, threads, reps, 1, enc, enc_len, nblocks);
+    for (size_t b = 0; b < nblocks; b++) { /* untimed: produce the blocks */
+        size_t off = b * block, bl = n - off < block ? n - off : block;
+        enc[b] = (uint8_t*)malloc(bl + 16);
+        long m = mlzo_encode(enc[b], bl + 16, src + off, bl, level);
+        enc_len[b] = m > 0 ? (size_t)m : 0;
+    }
+    double dt = bench_run(src, n, block, level, threads, reps, 1, enc, enc_len, nblocks, NULL);
     for (size_t b = 0; b < nblocks; b++) free(enc[b]);
     free(enc); free(enc_len);
     return dt;

@@ -40,6 +40,7 @@ def main():
     ap.add_argument("--bytes", type=int, default=100_000_000, help="uncompressed stream bytes per GPU (enwik8 = 1e8)")
     ap.add_argument("--level", type=int, default=1)
     ap.add_argument("--far", type=int, default=1)
+    ap.add_argument("--staged", type=int, default=-1, help="encoder tile bytes in LDS (1) or in place (0); -1 = library default")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--workload", default="text", choices=["text", "json", "random"])
     args = ap.parse_args()
@@ -64,6 +65,8 @@ def main():
 
     ctx = mz.Context(local)
     ctx.set_option(mz.OPT_ENCODE_FAR, args.far)
+    if args.staged >= 0:
+        ctx.set_option(6, args.staged)
 
     # ---- synthetic stream for this rank (weak scaling: every rank has its own S bytes) ----
     S = args.bytes

@@ -67,8 +67,11 @@ struct mlz_ctx {
     // options
     int decode_algo = 0;
     int encode_far = 1;
+    int encode_staged = 0;
     bool timing = false;
     int debug_status = 0;
+    bool prof_on = false;
+    DevBuf d_prof;
     hipEvent_t ev[T_COUNT][2] = {};
     bool ev_used[T_COUNT] = {};
 };
@@ -169,6 +172,12 @@ int encode_device_locked(mlz_ctx* c, hipStream_t st, int level, const uint8_t* d
         // LevelBalanced currently maps onto the same kernel with far matching forced on
         // (DESIGN.md "Levels").
         const bool far = (c->encode_far || level == MLZ_LEVEL_BALANCED) && maxlen > kTile;
+        static bool enc_attrs = false;
+        if (!enc_attrs) {
+            HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(encode_tiles_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, kEncLdsStaged));
+            HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(encode_tiles_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, kEncLdsStaged));
+            enc_attrs = true;
+        }
         if (far) {
             Timer t(c, T_FAR, st);
             const size_t words = (size_t(n) * (kLevels - 1) * epochs) << kFarBits;
@@ -179,12 +188,14 @@ int encode_device_locked(mlz_ctx* c, hipStream_t st, int level, const uint8_t* d
         }
         {
             Timer t(c, T_ENC_TILES, st);
-            if (far)
-                hipLaunchKernelGGL(encode_tiles_kernel<true>, dim3(tiles), dim3(64), 0, st, d_src, blocks, tile_block, c->d_scratch.as<uint8_t>(),
-                                   c->d_tile_size.as<uint32_t>(), c->d_far.as<uint32_t>(), epochs);
-            else
-                hipLaunchKernelGGL(encode_tiles_kernel<false>, dim3(tiles), dim3(64), 0, st, d_src, blocks, tile_block, c->d_scratch.as<uint8_t>(),
-                                   c->d_tile_size.as<uint32_t>(), (const uint32_t*)nullptr, epochs);
+            unsigned long long* prof = c->prof_on ? c->d_prof.as<unsigned long long>() : nullptr;
+            const uint32_t* ftab = far ? c->d_far.as<uint32_t>() : nullptr;
+#define MLZ_LAUNCH_ENC(F, S, LDS)                                                                                                         \
+    hipLaunchKernelGGL((encode_tiles_kernel<F, S>), dim3(tiles), dim3(64), LDS, st, d_src, blocks, tile_block, c->d_scratch.as<uint8_t>(), \
+                       c->d_tile_size.as<uint32_t>(), ftab, epochs, prof)
+            if (c->encode_staged) { if (far) MLZ_LAUNCH_ENC(true, true, kEncLdsStaged); else MLZ_LAUNCH_ENC(false, true, kEncLdsStaged); }
+            else { if (far) MLZ_LAUNCH_ENC(true, false, kEncLdsInPlace); else MLZ_LAUNCH_ENC(false, false, kEncLdsInPlace); }
+#undef MLZ_LAUNCH_ENC
         }
     }
     {
@@ -214,7 +225,8 @@ int decode_parallel(mlz_ctx* c, hipStream_t st, const uint8_t* d_src, uint8_t* d
     const size_t o_sout = o_entry + al(size_t(segs) * 4);
     const size_t o_slast = o_sout + al(size_t(segs) * 4);
     const size_t o_tstart = o_slast + al(size_t(segs) * 4);
-    const size_t o_done = o_tstart + al(size_t(tiles) * sizeof(TileStart));
+    const size_t o_mask = o_tstart + al(size_t(tiles) * sizeof(TileStart));
+    const size_t o_done = o_mask + al(size_t(segs) * 256 * 8);
     const size_t o_ticket = o_done + al(size_t(tiles) * 4);
     const size_t total = o_ticket + 256;
     HIPCHK(c, c->d_dec.ensure(total));
@@ -225,6 +237,7 @@ int decode_parallel(mlz_ctx* c, hipStream_t st, const uint8_t* d_src, uint8_t* d
     uint32_t* seg_out = reinterpret_cast<uint32_t*>(ws + o_sout);
     uint32_t* seg_last = reinterpret_cast<uint32_t*>(ws + o_slast);
     TileStart* tile_start = reinterpret_cast<TileStart*>(ws + o_tstart);
+    uint64_t* tok_mask = reinterpret_cast<uint64_t*>(ws + o_mask);
     uint32_t* tile_done = reinterpret_cast<uint32_t*>(ws + o_done);
     uint32_t* ticket = reinterpret_cast<uint32_t*>(ws + o_ticket);
     const BlockInfo* blocks = c->d_blocks.as<BlockInfo>();
@@ -257,13 +270,13 @@ int decode_parallel(mlz_ctx* c, hipStream_t st, const uint8_t* d_src, uint8_t* d
         hipLaunchKernelGGL(dec_index_b_kernel, dim3((n + 63) / 64), dim3(64), 0, st, blocks, dec, seg_out, seg_last, seg_entry, n);
         if (segs)
             hipLaunchKernelGGL(dec_index_c_kernel, dim3(segs), dim3(256), kIndexLds, st, d_src, blocks, seg_block, dec, seg_entry, seg_out, seg_last,
-                               tile_start);
+                               tile_start, tok_mask);
     }
     {
         Timer t(c, T_DEC_EXEC, st);
         if (tiles)
-            hipLaunchKernelGGL(dec_exec_kernel, dim3(tiles), dim3(64), kTile, st, d_src, d_dst, blocks, tile_block, dec, tile_start, tile_done, ticket,
-                               tiles);
+            hipLaunchKernelGGL(dec_exec_kernel, dim3(tiles), dim3(64), kTile, st, d_src, d_dst, blocks, tile_block, dec, tile_start, tok_mask, tile_done, ticket,
+                               tiles, c->prof_on ? c->d_prof.as<unsigned long long>() : nullptr);
         hipLaunchKernelGGL(dec_finish_kernel, dim3((n + 63) / 64), dim3(64), 0, st, dec, d_out_len, n, c->debug_status);
     }
     HIPCHK(c, hipGetLastError());
@@ -355,7 +368,7 @@ void mlz_destroy(mlz_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
-    for (DevBuf* b : {&c->d_blocks, &c->d_tile_block, &c->d_seg_block, &c->d_scratch, &c->d_tile_size, &c->d_tile_out, &c->d_flags, &c->d_far, &c->d_dec, &c->d_in, &c->d_out, &c->d_len})
+    for (DevBuf* b : {&c->d_prof, &c->d_blocks, &c->d_tile_block, &c->d_seg_block, &c->d_scratch, &c->d_tile_size, &c->d_tile_out, &c->d_flags, &c->d_far, &c->d_dec, &c->d_in, &c->d_out, &c->d_len})
         b->release();
     if (c->pinned) (void)hipHostFree(c->pinned);
     for (int i = 0; i < T_COUNT; i++)
@@ -474,7 +487,19 @@ int mlz_set_option(mlz_ctx* c, int opt, int64_t value) {
     switch (opt) {
     case MLZ_OPT_DECODE_ALGO: c->decode_algo = int(value); return 0;
     case MLZ_OPT_ENCODE_FAR: c->encode_far = int(value); return 0;
+    case 6: c->encode_staged = int(value); return 0;  // tuning: stage tile bytes in LDS (1) or read them in place (0)
     case 3: c->debug_status = int(value); return 0;  // debug: report failure sites in the error code
+    case 4: {  // debug: per-phase cycle counters (16 x u64: 0-7 encode, 8-15 decode)
+        c->prof_on = value != 0;
+        if (c->prof_on) { if (c->d_prof.ensure(256) != hipSuccess) return -MLZ_ERR_HIP; if (hipMemset(c->d_prof.p, 0, 256) != hipSuccess) return -MLZ_ERR_HIP; }
+        return 0;
+    }
+    case 5: {  // debug: read the counters back into a host buffer whose address is `value`
+        if (!c->d_prof.p) return -MLZ_ERR_ARG;
+        if (hipDeviceSynchronize() != hipSuccess) return -MLZ_ERR_HIP;
+        if (hipMemcpy(reinterpret_cast<void*>(value), c->d_prof.p, 128, hipMemcpyDeviceToHost) != hipSuccess) return -MLZ_ERR_HIP;
+        return 0;
+    }
     case MLZ_TIMER_ENABLE: c->timing = value != 0; for (bool& u : c->ev_used) u = false; return 0;
     default: return -MLZ_ERR_ARG;
     }

@@ -6,9 +6,12 @@ namespace mlz {
 
 // Tile = the unit of intra-block parallelism (DESIGN.md "Tiles").  Each tile of a block is
 // encoded by one wavefront into an independent token sub-stream and decoded by one wavefront.
-constexpr int kTileLog = 16;
+#ifndef MLZ_TILE_LOG
+#define MLZ_TILE_LOG 15
+#endif
+constexpr int kTileLog = MLZ_TILE_LOG;
 constexpr uint32_t kTile = 1u << kTileLog;           // 64 KiB of uncompressed data
-constexpr uint32_t kTileScratch = kTile + kTile / 16 + 64;  // worst-case tokens per tile
+constexpr uint32_t kTileScratch = kTile + kTile / 16 + 2048;  // worst-case tokens per tile + flush slack (multiple of 16)
 
 struct BlockInfo {
     uint64_t src_off, src_len, dst_off, dst_cap;

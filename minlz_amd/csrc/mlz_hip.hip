@@ -226,7 +226,8 @@ int decode_parallel(mlz_ctx* c, hipStream_t st, const uint8_t* d_src, uint8_t* d
     const size_t o_slast = o_sout + al(size_t(segs) * 4);
     const size_t o_tstart = o_slast + al(size_t(segs) * 4);
     const size_t o_mask = o_tstart + al(size_t(tiles) * sizeof(TileStart));
-    const size_t o_done = o_mask + al(size_t(segs) * 256 * 8);
+    const size_t o_order = o_mask + al(size_t(segs) * 256 * 8);
+    const size_t o_done = o_order + al(size_t(tiles) * 4);
     const size_t o_ticket = o_done + al(size_t(tiles) * 4);
     const size_t total = o_ticket + 256;
     HIPCHK(c, c->d_dec.ensure(total));
@@ -238,6 +239,7 @@ int decode_parallel(mlz_ctx* c, hipStream_t st, const uint8_t* d_src, uint8_t* d
     uint32_t* seg_last = reinterpret_cast<uint32_t*>(ws + o_slast);
     TileStart* tile_start = reinterpret_cast<TileStart*>(ws + o_tstart);
     uint64_t* tok_mask = reinterpret_cast<uint64_t*>(ws + o_mask);
+    uint32_t* order = reinterpret_cast<uint32_t*>(ws + o_order);
     uint32_t* tile_done = reinterpret_cast<uint32_t*>(ws + o_done);
     uint32_t* ticket = reinterpret_cast<uint32_t*>(ws + o_ticket);
     const BlockInfo* blocks = c->d_blocks.as<BlockInfo>();
@@ -271,11 +273,12 @@ int decode_parallel(mlz_ctx* c, hipStream_t st, const uint8_t* d_src, uint8_t* d
         if (segs)
             hipLaunchKernelGGL(dec_index_c_kernel, dim3(segs), dim3(256), kIndexLds, st, d_src, blocks, seg_block, dec, seg_entry, seg_out, seg_last,
                                tile_start, tok_mask);
+        if (tiles) hipLaunchKernelGGL(dec_schedule_kernel, dim3(1), dim3(256), 0, st, blocks, tile_block, dec, order, tiles);
     }
     {
         Timer t(c, T_DEC_EXEC, st);
         if (tiles)
-            hipLaunchKernelGGL(dec_exec_kernel, dim3(tiles), dim3(64), kTile, st, d_src, d_dst, blocks, tile_block, dec, tile_start, tok_mask, tile_done, ticket,
+            hipLaunchKernelGGL(dec_exec_kernel, dim3(tiles), dim3(64), kTile, st, d_src, d_dst, blocks, tile_block, dec, tile_start, tok_mask, order, tile_done, ticket,
                                tiles, c->prof_on ? c->d_prof.as<unsigned long long>() : nullptr);
         hipLaunchKernelGGL(dec_finish_kernel, dim3((n + 63) / 64), dim3(64), 0, st, dec, d_out_len, n, c->debug_status);
     }

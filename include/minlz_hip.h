@@ -95,6 +95,16 @@ int mlz_encode_batch_device(mlz_ctx* ctx, void* stream, int level, const uint8_t
 int mlz_decode_batch_device(mlz_ctx* ctx, void* stream, const uint8_t* d_src, uint8_t* d_dst,
                             const mlz_block_desc* desc, int n_blocks, int64_t* d_out_len);
 
+/* ---- masked CRC32C (stream chunks) ----
+ * crc(b) of minlz.go:133-140: Castagnoli CRC, rotated by 15, plus 0xa282ead8; computed over the
+ * uncompressed bytes of each block (writer.go:887, reader.go:341-351).
+ * mlz_crc: host buffer, returns the 32-bit value (>= 0) or -MLZ_ERR_*.
+ * mlz_crc_batch_device: blocks described by desc[i].src_off/src_len relative to d_base; d_out[i]
+ * (uint32, device) receives the masked CRC of block i. */
+int64_t mlz_crc(mlz_ctx* ctx, const uint8_t* src, size_t n);
+int mlz_crc_batch_device(mlz_ctx* ctx, void* stream, const uint8_t* d_base, const mlz_block_desc* desc, int n_blocks,
+                         uint32_t* d_out);
+
 /* ---- tuning / introspection (not part of the reference surface) ---- */
 #define MLZ_OPT_DECODE_ALGO 1  /* 0 = parallel (default), 1 = serial one-wave-per-block */
 #define MLZ_OPT_ENCODE_FAR 2   /* 0 = tile-local matches only, 1 = + far matches (default) */

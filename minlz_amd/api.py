@@ -99,6 +99,12 @@ class Context:
         if r:
             _raise(r, self)
 
+    def crc_batch_device(self, stream, d_base, descs, d_out_u32):
+        arr = (BlockDesc * len(descs))(*descs) if not isinstance(descs, C.Array) else descs
+        r = _lib.lib().mlz_crc_batch_device(self.handle, stream, d_base, arr, len(arr), d_out_u32)
+        if r:
+            _raise(r, self)
+
     def decode_batch_device(self, stream, d_src, d_dst, descs, d_out_len):
         arr = (BlockDesc * len(descs))(*descs) if not isinstance(descs, C.Array) else descs
         r = _lib.lib().mlz_decode_batch_device(self.handle, stream, d_src, d_dst, arr, len(arr), d_out_len)
@@ -200,6 +206,16 @@ def Decode(src, ctx=None, guard=0):
 def AppendDecoded(dst, src, ctx=None):
     """decode.go:85-103"""
     return bytes(dst) + Decode(src, ctx)
+
+
+def crc(b, ctx=None):
+    """crc(b) of minlz.go:133-140 (masked CRC32C), computed on the device."""
+    ctx = ctx or default_context()
+    a = _np(b)
+    r = _lib.lib().mlz_crc(ctx.handle, _ptr(a), a.size)
+    if r < 0:
+        _raise(r, ctx)
+    return int(r)
 
 
 def encode_block(src, level=LevelFastest, ctx=None):

@@ -19,6 +19,7 @@
 #include "mlz_encode.hip.inc"
 #include "mlz_decode_serial.hip.inc"
 #include "mlz_decode.hip.inc"
+#include "mlz_crc.hip.inc"
 
 using namespace mlz;
 
@@ -39,8 +40,8 @@ struct DevBuf {
     template <class T> T* as() { return static_cast<T*>(p); }
 };
 
-enum { T_FAR = 0, T_ENC_TILES, T_ENC_LAYOUT, T_ENC_GATHER, T_DEC_PARSE, T_DEC_CHAIN, T_DEC_INDEX, T_DEC_EXEC, T_DEC_SERIAL, T_COUNT };
-const char* kTimerNames[T_COUNT] = {"enc_far_build", "enc_tiles", "enc_layout", "enc_gather", "dec_parse", "dec_chain", "dec_index", "dec_exec", "dec_serial"};
+enum { T_FAR = 0, T_ENC_TILES, T_ENC_LAYOUT, T_ENC_GATHER, T_DEC_PARSE, T_DEC_CHAIN, T_DEC_INDEX, T_DEC_EXEC, T_DEC_SERIAL, T_CRC, T_COUNT };
+const char* kTimerNames[T_COUNT] = {"enc_far_build", "enc_tiles", "enc_layout", "enc_gather", "dec_parse", "dec_chain", "dec_index", "dec_exec", "dec_serial", "crc"};
 
 }  // namespace
 
@@ -63,7 +64,7 @@ struct mlz_ctx {
     // decode workspace
     DevBuf d_dec;
     // host-pointer staging
-    DevBuf d_in, d_out, d_len;
+    DevBuf d_in, d_out, d_len, d_crc;
     // options
     int decode_algo = 0;
     int encode_far = 1;
@@ -302,6 +303,31 @@ int decode_device_locked(mlz_ctx* c, hipStream_t st, const uint8_t* d_src, uint8
     return decode_parallel(c, st, d_src, d_dst, desc, n, d_out_len, raw_body);
 }
 
+int crc_device_locked(mlz_ctx* c, hipStream_t st, const uint8_t* d_base, const mlz_block_desc* desc, int n, uint32_t* d_out) {
+    if (n <= 0) return 0;
+    HIPCHK(c, hipSetDevice(c->device));
+    uint32_t tiles = 0;
+    int r = upload_blocks(c, st, desc, n, false, &tiles);
+    if (r) return r;
+    static CrcPow pw;
+    static bool pw_init = false;
+    if (!pw_init) {
+        uint32_t p = 1u << 30;  // x^1
+        pw.x2n[0] = p;
+        for (int k = 1; k < 32; k++) pw.x2n[k] = p = crc_mulmod(p, p);
+        pw_init = true;
+    }
+    uint64_t maxlen = 0;
+    for (int i = 0; i < n; i++) maxlen = std::max<uint64_t>(maxlen, desc[i].src_len);
+    Timer t(c, T_CRC, st);
+    HIPCHK(c, hipMemsetAsync(d_out, 0, sizeof(uint32_t) * n, st));
+    const uint32_t groups = uint32_t((maxlen + kCrcGroup - 1) / kCrcGroup);
+    if (groups) hipLaunchKernelGGL(crc_kernel, dim3(groups, n), dim3(256), 0, st, d_base, c->d_blocks.as<BlockInfo>(), pw, d_out);
+    hipLaunchKernelGGL(crc_mask_kernel, dim3((n + 255) / 256), dim3(256), 0, st, d_out, n);
+    HIPCHK(c, hipGetLastError());
+    return 0;
+}
+
 // ---- host-pointer plumbing: pack blocks into one device buffer, run, copy back ----
 int host_batch(mlz_ctx* c, bool encode, int level, int n, const uint8_t* const* src, const size_t* src_len, uint8_t* const* dst, const size_t* dst_cap,
                int64_t* out_len, bool with_header, const size_t* decoded_len /* decode_block only */) {
@@ -371,7 +397,7 @@ void mlz_destroy(mlz_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
-    for (DevBuf* b : {&c->d_prof, &c->d_blocks, &c->d_tile_block, &c->d_seg_block, &c->d_scratch, &c->d_tile_size, &c->d_tile_out, &c->d_flags, &c->d_far, &c->d_dec, &c->d_in, &c->d_out, &c->d_len})
+    for (DevBuf* b : {&c->d_crc, &c->d_prof, &c->d_blocks, &c->d_tile_block, &c->d_seg_block, &c->d_scratch, &c->d_tile_size, &c->d_tile_out, &c->d_flags, &c->d_far, &c->d_dec, &c->d_in, &c->d_out, &c->d_len})
         b->release();
     if (c->pinned) (void)hipHostFree(c->pinned);
     for (int i = 0; i < T_COUNT; i++)
@@ -524,5 +550,27 @@ int mlz_get_timers(mlz_ctx* c, float* ms, int cap) {
 }
 
 const char* mlz_timer_name(int idx) { return idx >= 0 && idx < T_COUNT ? kTimerNames[idx] : ""; }
+
+int mlz_crc_batch_device(mlz_ctx* c, void* stream, const uint8_t* d_base, const mlz_block_desc* desc, int n, uint32_t* d_out) {
+    if (!c || !desc || n < 0 || !d_out) return -MLZ_ERR_ARG;
+    std::lock_guard<std::mutex> lk(c->mu);
+    return crc_device_locked(c, static_cast<hipStream_t>(stream), d_base, desc, n, d_out);
+}
+
+int64_t mlz_crc(mlz_ctx* c, const uint8_t* src, size_t n) {
+    if (!c || (!src && n)) return -MLZ_ERR_ARG;
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, c->d_in.ensure(n + 64));
+    HIPCHK(c, c->d_crc.ensure(64));
+    if (n) HIPCHK(c, hipMemcpyAsync(c->d_in.p, src, n, hipMemcpyHostToDevice, c->stream));
+    mlz_block_desc d{0, n, 0, 0};
+    int r = crc_device_locked(c, c->stream, c->d_in.as<uint8_t>(), &d, 1, c->d_crc.as<uint32_t>());
+    if (r) return r;
+    uint32_t v = 0;
+    HIPCHK(c, hipMemcpyAsync(&v, c->d_crc.p, 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return int64_t(v);
+}
 
 }  // extern "C"

@@ -1,0 +1,266 @@
+"""Stream framing mirror of the reference's Writer / Reader (writer.go, reader.go, SPEC.md:272-431).
+
+Per block the Writer emits `[type][len24][masked crc32c of the uncompressed bytes][body]`:
+type 0x02 with body `uvarint(N) tokens` when the block compressed, 0x01 with the raw bytes
+otherwise (writer.go:876-910); the stream starts with `ff 06 00 00 "MinLz" (log2(blockSize)-10)`
+(writer.go:1553-1556) and ends with the EOF chunk `20 len uvarint(total)` (writer.go:1063-1074).
+Blocks are handed to a *backend* in batches — one launch per batch on the GPU instead of one
+goroutine per block (writer.go:501-560, reader.go:830-859).  No index / padding / search tables.
+
+Backends: HipBackend (the product: everything on the device through the C ABI).  Tests inject an
+oracle-based backend to exercise this host logic without a GPU.
+"""
+import io
+
+from . import api
+
+MAGIC = b"\xff\x06\x00\x00MinLz"
+CHUNK_UNCOMPRESSED, CHUNK_MINLZ, CHUNK_MINLZ_COMPCRC, CHUNK_EOF, CHUNK_STREAM_ID = 0x01, 0x02, 0x03, 0x20, 0xFF
+MIN_BLOCK, MAX_BLOCK, DEFAULT_BLOCK = 4 << 10, 8 << 20, 2 << 20  # minlz.go:98-106
+
+
+def put_uvarint(v):
+    out = bytearray()
+    while v >= 0x80:
+        out.append((v & 0x7F) | 0x80)
+        v >>= 7
+    out.append(v)
+    return bytes(out)
+
+
+def uvarint(b, pos=0):
+    """binary.Uvarint: (value, bytes read); n == 0 -> buffer too small, n < 0 -> overflow."""
+    x = s = 0
+    for i in range(pos, len(b)):
+        c = b[i]
+        if i - pos == 10:
+            return 0, -(i - pos + 1)
+        if c < 0x80:
+            if i - pos == 9 and c > 1:
+                return 0, -(i - pos + 1)
+            return x | (c << s), i - pos + 1
+        x |= (c & 0x7F) << s
+        s += 7
+    return 0, 0
+
+
+class HipBackend:
+    """Block work on the MI355X through the C ABI (no CPU fallback)."""
+
+    def __init__(self, ctx=None):
+        self.ctx = ctx or api.default_context()
+
+    def encode_blocks(self, blocks, level):
+        """-> list of `uvarint(N) tokens` bodies, or None where the block is stored raw."""
+        encs = api.encode_batch(blocks, level, self.ctx)
+        out = []
+        for b, e in zip(blocks, encs):
+            stored = len(b) == 0 or e[:2] == b"\x00\x00"
+            out.append(None if stored else e[1:])
+        return out
+
+    def decode_bodies(self, bodies):
+        """bodies: list of `uvarint(N) tokens` -> list of decoded blocks (raises ErrCorrupt)."""
+        return api.decode_batch([b"\x00" + b for b in bodies], self.ctx)
+
+    def crcs(self, blocks):
+        return [api.crc(b, self.ctx) for b in blocks]
+
+
+class Writer:
+    """NewWriter(w, WriterLevel(level), WriterBlockSize(bs), WriterConcurrency(n)) (writer.go:35-86)."""
+
+    def __init__(self, w, level=api.LevelBalanced, block_size=DEFAULT_BLOCK, concurrency=16, backend=None):
+        if not (MIN_BLOCK <= block_size <= MAX_BLOCK):
+            raise ValueError("minlz: block size must be 4KiB..8MiB")  # writer.go:1238-1246
+        if level not in (api.LevelUncompressed, api.LevelFastest, api.LevelBalanced):
+            raise api.ErrInvalidLevel()
+        self.w, self.level, self.block_size, self.batch = w, level, block_size, max(1, concurrency)
+        self.backend = backend or HipBackend()
+        self.buf = bytearray()
+        self.wrote_header = False
+        self.written = 0          # Written(): compressed bytes so far (writer.go:1041)
+        self.uncomp_written = 0
+        self.closed = False
+
+    def _emit(self, b):
+        self.w.write(b)
+        self.written += len(b)
+
+    def _flush_blocks(self, final):
+        bs = self.block_size
+        nfull = len(self.buf) // bs
+        take = len(self.buf) if final else nfull * bs
+        if take == 0:
+            return
+        data = bytes(self.buf[:take])
+        del self.buf[:take]
+        blocks = [data[i:i + bs] for i in range(0, take, bs)]
+        if not self.wrote_header:  # header goes out with the first block (writer.go:463-467)
+            self.wrote_header = True
+            self._emit(MAGIC + bytes([(bs - 1).bit_length() - 10]))
+        for g in range(0, len(blocks), self.batch):
+            grp = blocks[g:g + self.batch]
+            bodies = self.backend.encode_blocks(grp, self.level) if self.level != api.LevelUncompressed else [None] * len(grp)
+            crcs = self.backend.crcs(grp)
+            for blk, body, crc in zip(grp, bodies, crcs):
+                if body is not None:
+                    ctype, payload = CHUNK_MINLZ, body
+                else:
+                    ctype, payload = CHUNK_UNCOMPRESSED, blk
+                clen = 4 + len(payload)
+                self._emit(bytes([ctype, clen & 0xFF, (clen >> 8) & 0xFF, (clen >> 16) & 0xFF]) + crc.to_bytes(4, "little") + payload)
+                self.uncomp_written += len(blk)
+
+    def Write(self, p):
+        if self.closed:
+            raise ValueError("minlz: Writer is closed")
+        self.buf += p
+        if len(self.buf) >= self.block_size * self.batch:
+            self._flush_blocks(False)
+        return len(p)
+
+    def EncodeBuffer(self, buf):  # writer.go:441
+        self.Write(buf)
+        self._flush_blocks(True)
+
+    def Flush(self):
+        self._flush_blocks(True)
+
+    def Close(self):
+        if self.closed:
+            return
+        self._flush_blocks(True)
+        v = put_uvarint(self.uncomp_written)
+        self._emit(bytes([CHUNK_EOF, len(v), 0, 0]) + v)  # writer.go:1063-1074
+        self.closed = True
+
+    def Written(self):
+        return self.written
+
+
+class Reader:
+    """NewReader(r, ReaderMaxBlockSize(n), ReaderIgnoreCRC()) (reader.go:42-125); MinLZ streams only."""
+
+    def __init__(self, r, max_block_size=MAX_BLOCK, ignore_crc=False, batch=16, backend=None):
+        self.r = r if hasattr(r, "read") else io.BytesIO(r)
+        self.max_block_org = max_block_size
+        self.ignore_crc = ignore_crc
+        self.batch = max(1, batch)
+        self.backend = backend or HipBackend()
+
+    def _read_full(self, n, allow_eof=False):
+        b = self.r.read(n)
+        if len(b) == 0 and allow_eof:
+            return None
+        if len(b) != n:
+            raise api.ErrCorrupt("unexpected EOF")  # readFull, reader.go:196-204
+        return b
+
+    def _drain(self, pending, out):
+        """Decode the queued chunks in one batch and append the results in stream order."""
+        if not pending:
+            return
+        comp = [(i, p) for i, p in enumerate(pending) if p[0] == "c"]
+        decoded = self.backend.decode_bodies([p[1] for _, p in comp]) if comp else []
+        res = [None] * len(pending)
+        for (i, _), d in zip(comp, decoded):
+            res[i] = d
+        for i, p in enumerate(pending):
+            if p[0] == "u":
+                res[i] = p[1]
+        if not self.ignore_crc:
+            crcs = self.backend.crcs(res)
+            for p, c in zip(pending, crcs):
+                if c != p[2]:
+                    raise api.ErrCRC()
+        for d in res:
+            out.write(d)
+        pending.clear()
+
+    def WriteTo(self, w):
+        """Reader.WriteTo / DecodeConcurrent (reader.go:575-992): returns bytes written."""
+        max_block = self.max_block_org
+        read_header = want_eof = False
+        stream_out = 0
+        pending = []
+        while True:
+            hdr = self._read_full(4, allow_eof=not want_eof)
+            if hdr is None:
+                break
+            ctype = hdr[0]
+            clen = hdr[1] | hdr[2] << 8 | hdr[3] << 16
+            if not read_header:
+                if ctype == CHUNK_STREAM_ID:
+                    read_header = True
+                elif ctype <= 0x3F and ctype != CHUNK_EOF:
+                    raise api.ErrCorrupt("no stream header")  # reader.go:273-283
+            if ctype in (CHUNK_MINLZ, CHUNK_MINLZ_COMPCRC):
+                if clen < 4 or clen > api.MaxEncodedLen(max_block) + 4:
+                    raise api.ErrCorrupt()
+                buf = self._read_full(clen)
+                crc = int.from_bytes(buf[:4], "little")
+                n, hl = uvarint(buf, 4)
+                if hl <= 0 or n > 0xFFFFFFFF:
+                    raise api.ErrCorrupt()
+                if n > max_block:
+                    raise api.ErrTooLarge()
+                body_len = clen - 4 - hl
+                if n == 0 or n < body_len:
+                    raise api.ErrCorrupt()  # reader.go:327
+                if ctype == CHUNK_MINLZ_COMPCRC:
+                    raise api.ErrUnsupported("chunk 0x03 (CRC over compressed bytes)")
+                pending.append(("c", buf[4:], crc))
+                stream_out += n
+            elif ctype == CHUNK_UNCOMPRESSED:
+                if clen < 4 or clen > api.MaxEncodedLen(max_block) + 4:
+                    raise api.ErrCorrupt()
+                crcb = self._read_full(4)
+                n = clen - 4
+                if n > max_block:
+                    raise api.ErrTooLarge()
+                pending.append(("u", self._read_full(n), int.from_bytes(crcb, "little")))
+                stream_out += n
+            elif ctype == CHUNK_EOF:
+                if clen > 10:
+                    raise api.ErrCorrupt()
+                if clen:
+                    buf = self._read_full(clen)
+                    want, vn = uvarint(buf)
+                    if vn != clen or want != stream_out:
+                        raise api.ErrCorrupt("EOF length mismatch")  # reader.go:476-491
+                want_eof = read_header = False
+            elif ctype == CHUNK_STREAM_ID:
+                if clen != 6:
+                    raise api.ErrCorrupt()
+                body = self._read_full(6)
+                if body[:5] != b"MinLz":
+                    raise api.ErrUnsupported("not a MinLZ stream")
+                if body[5] & 0xC0:
+                    raise api.ErrCorrupt()
+                lg = (body[5] & 15) + 10
+                if lg > 23:
+                    raise api.ErrCorrupt()
+                max_block = 1 << lg
+                if max_block > self.max_block_org:
+                    raise api.ErrTooLarge()
+                self._drain(pending, w)
+                stream_out = 0
+                want_eof = True
+            elif ctype == 0x00:
+                raise api.ErrUnsupported("legacy S2/Snappy chunk")
+            elif ctype <= 0x3F:
+                raise api.ErrUnsupported("reserved unskippable chunk")  # reader.go:530-536
+            else:
+                self._read_full(clen)  # skippable
+            if len(pending) >= self.batch:
+                self._drain(pending, w)
+        self._drain(pending, w)
+        return None
+
+    DecodeConcurrent = WriteTo
+
+    def ReadAll(self):
+        out = io.BytesIO()
+        self.WriteTo(out)
+        return out.getvalue()

@@ -27,7 +27,10 @@ def stale():
 def build(force=False, verbose=False):
     if not force and not stale():
         return SO
-    cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-o", SO, SRC]
+    # unaligned-ds-access: the ROCm runtime runs compute queues with unaligned LDS access enabled (verified on
+    # MI355X, tools/ldsalign_test); telling the compiler lets unaligned 4/8-byte LDS copies be single DS ops.
+    cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Xclang", "-target-feature", "-Xclang", "+unaligned-ds-access",
+           "-Wno-unused-command-line-argument", "-o", SO, SRC]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

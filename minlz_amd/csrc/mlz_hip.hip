@@ -248,7 +248,7 @@ int decode_parallel(mlz_ctx* c, hipStream_t st, const uint8_t* d_src, uint8_t* d
     const uint32_t* seg_block = c->d_seg_block.as<uint32_t>();
     static bool attrs = false;
     if (!attrs) {
-        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(dec_exit_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kSeg * 4 + kSeg + 64));
+        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(dec_exit_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kExitLds));
         HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(dec_index_a_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kIndexLds));
         HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(dec_index_c_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kIndexLds));
         HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(dec_exec_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kTile));
@@ -260,7 +260,7 @@ int decode_parallel(mlz_ctx* c, hipStream_t st, const uint8_t* d_src, uint8_t* d
         HIPCHK(c, hipMemsetAsync(ws + o_done, 0, o_ticket + 256 - o_done, st));
         hipLaunchKernelGGL(dec_header_kernel, dim3((n + 63) / 64), dim3(64), 0, st, d_src, blocks, dec, n, raw_body ? 1 : 0);
         if (segs)
-            hipLaunchKernelGGL(dec_exit_kernel, dim3(segs), dim3(256), kSeg * 4 + kSeg + 64, st, d_src, blocks, seg_block, dec, exit_tab);
+            hipLaunchKernelGGL(dec_exit_kernel, dim3(segs), dim3(256), kExitLds, st, d_src, blocks, seg_block, dec, exit_tab);
     }
     {
         Timer t(c, T_DEC_CHAIN, st);

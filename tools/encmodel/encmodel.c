@@ -28,6 +28,8 @@ typedef struct {
     int wave;         /* lanes per step (64) */
     int nlevels;      /* leveled tiles: far sources must be in lower-level tiles (0 = unconstrained) */
     int lpat;         /* level pattern id */
+    int pw_tiles;     /* >0: far table = per-tile table over the last pw_tiles lower-level tiles (most recent wins) */
+    int pw_bits;
 } params;
 
 static inline uint64_t ld64(const uint8_t* p) { uint64_t v; memcpy(&v, p, 8); return v; }
@@ -91,12 +93,24 @@ size_t model_block(const uint8_t* src, size_t n, const params* P, stats* st) {
     }
     uint8_t* depth = (uint8_t*)calloc(n + 8, 1);
     uint16_t* table = (uint16_t*)malloc(sizeof(uint16_t) << P->hash_bits);
+    uint32_t* pwtab = P->pw_tiles ? (uint32_t*)malloc(sizeof(uint32_t) << P->pw_bits) : NULL;
     uint8_t* hole = (uint8_t*)malloc(T + 8);
     for (size_t t = 0; t < ntiles; t++) {
         size_t base = t * T, tl = n - base < T ? n - base : T;
         const uint8_t* s = src + base;
         memset(table, 0, sizeof(uint16_t) << P->hash_bits);
         memset(hole, 0, T + 8);
+        if (pwtab) {
+            memset(pwtab, 0xff, sizeof(uint32_t) << P->pw_bits);
+            int mylv0 = tile_level(t, P), got = 0;
+            /* oldest first so that the most recent source tile wins */
+            long srcs[64]; 
+            for (long tt = (long)t - 1; tt >= 0 && got < P->pw_tiles && (t - tt) * T <= 2162687 - T; tt--) if (tile_level(tt, P) < mylv0) srcs[got++] = tt;
+            for (int gi = got - 1; gi >= 0; gi--) {
+                size_t b0 = (size_t)srcs[gi] * T;
+                for (size_t q = b0; q + 8 <= b0 + T && q + 8 <= n; q += P->far_stride) pwtab[hashN(ld64(src + q), 8, P->pw_bits)] = (uint32_t)q;
+            }
+        }
         size_t cur = 0, next_emit = 0, out = 0, miss = 0;
         size_t rep = 0;
         const int W = P->wave;
@@ -128,7 +142,17 @@ size_t model_block(const uint8_t* src, size_t n, const params* P, stats* st) {
                     if (l >= 4 && (!brep || l > best + 1)) { if (!brep || l > best + 1) { best = l; boff = p - cand[i]; brep = 0; } }
                 }
                 int mylv = tile_level(t, P);
-                if (P->far && (!P->nlevels || mylv > 0)) {
+                if (pwtab && mylv > 0) {
+                    uint64_t v = ld64(s + p);
+                    uint32_t q = pwtab[hashN(v, 8, P->pw_bits)];
+                    if (q != 0xffffffffu && q < base) {
+                        size_t off = base + p - q;
+                        size_t srcleft = T - (q & (T - 1));
+                        size_t ml = maxl < srcleft ? maxl : srcleft;
+                        size_t l = mlen(s + p, src + q, ml);
+                        if (off <= 2162687 && l >= (size_t)P->far_min && l > best + 2) { best = l; boff = off; brep = 0; bfar = 1; }
+                    }
+                } else if (P->far && (!P->nlevels || mylv > 0)) {
                     uint64_t v = ld64(s + p);
                     uint32_t h = hashN(v, 8, P->far_bits);
                     size_t ep = (base + p) >> P->epoch_log;
@@ -182,7 +206,7 @@ size_t model_block(const uint8_t* src, size_t n, const params* P, stats* st) {
         if (out > tl + 4) out = tl + 4;
         total += out;
     }
-    free(table); free(hole); free(far_tab); free(depth);
+    free(table); free(hole); free(far_tab); free(depth); free(pwtab);
     if (st) st->out += total;
     return total;
 }

@@ -165,8 +165,18 @@ def main():
     if dom:
         alg = S + C_total
         ach = alg / 1e9 / (kavg[dom] / 1e3)
+        # HBM-side bytes per launch from rocprofv3 PMC passes (tools/pmc_run.sh -> tools/pmc_traffic.py), recorded for
+        # this exact workload; null when no matching measurement is committed
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tpath):
+            tj = json.load(open(tpath))
+            kname = {"enc_tiles": "encode_tiles_kernel<true, false>", "dec_exec": "dec_exec_kernel", "enc_far_build": "far_build_kernel",
+                     "dec_parse": "dec_exit_kernel"}.get(dom)
+            if tj.get("workload_bytes") == S and args.workload == "text" and kname in tj.get("kernels", {}):
+                traffic = tj["kernels"][kname]["traffic"]
         roofline = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None,
+                    "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
                     "algorithmic_bytes_per_launch": alg, "avg_launch_ms": round(kavg[dom], 4)}
 
     cpu = None

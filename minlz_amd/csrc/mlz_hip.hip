@@ -183,9 +183,13 @@ int encode_device_locked(mlz_ctx* c, hipStream_t st, int level, const uint8_t* d
             Timer t(c, T_FAR, st);
             const size_t words = (size_t(n) * (kLevels - 1) * epochs) << kFarBits;
             HIPCHK(c, c->d_far.ensure(words * 4));
-            HIPCHK(c, hipMemsetAsync(c->d_far.p, 0xff, words * 4, st));
-            dim3 grid(std::max<uint32_t>(1, std::min<uint32_t>(512, uint32_t((maxlen / kFarStride + 255) / 256))), n);
-            hipLaunchKernelGGL(far_build_kernel, grid, dim3(256), 0, st, d_src, blocks, c->d_far.as<uint32_t>(), epochs);
+            static bool far_attr = false;
+            if (!far_attr) {
+                HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(far_build_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 4u << kFarSliceBits));
+                far_attr = true;
+            }
+            hipLaunchKernelGGL(far_build_kernel, dim3(kFarSlices, (kLevels - 1) * epochs, n), dim3(1024), 4u << kFarSliceBits, st, d_src, blocks,
+                               c->d_far.as<uint32_t>(), epochs);
         }
         {
             Timer t(c, T_ENC_TILES, st);

@@ -231,7 +231,7 @@ int decode_parallel(mlz_ctx* c, hipStream_t st, const uint8_t* d_src, uint8_t* d
     const size_t o_slast = o_sout + al(size_t(segs) * 4);
     const size_t o_tstart = o_slast + al(size_t(segs) * 4);
     const size_t o_mask = o_tstart + al(size_t(tiles) * sizeof(TileStart));
-    const size_t o_order = o_mask + al(size_t(segs) * 256 * 8);
+    const size_t o_order = o_mask + al(size_t(segs) * kSegThreads * 8);
     const size_t o_done = o_order + al(size_t(tiles) * 4);
     const size_t o_ticket = o_done + al(size_t(tiles) * 4);
     const size_t total = o_ticket + 256;
@@ -264,7 +264,7 @@ int decode_parallel(mlz_ctx* c, hipStream_t st, const uint8_t* d_src, uint8_t* d
         HIPCHK(c, hipMemsetAsync(ws + o_done, 0, o_ticket + 256 - o_done, st));
         hipLaunchKernelGGL(dec_header_kernel, dim3((n + 63) / 64), dim3(64), 0, st, d_src, blocks, dec, n, raw_body ? 1 : 0);
         if (segs)
-            hipLaunchKernelGGL(dec_exit_kernel, dim3(segs), dim3(256), kExitLds, st, d_src, blocks, seg_block, dec, exit_tab);
+            hipLaunchKernelGGL(dec_exit_kernel, dim3(segs), dim3(kSegThreads), kExitLds, st, d_src, blocks, seg_block, dec, exit_tab);
     }
     {
         Timer t(c, T_DEC_CHAIN, st);
@@ -273,10 +273,10 @@ int decode_parallel(mlz_ctx* c, hipStream_t st, const uint8_t* d_src, uint8_t* d
     {
         Timer t(c, T_DEC_INDEX, st);
         if (segs)
-            hipLaunchKernelGGL(dec_index_a_kernel, dim3(segs), dim3(256), kIndexLds, st, d_src, blocks, seg_block, dec, seg_entry, seg_out, seg_last);
+            hipLaunchKernelGGL(dec_index_a_kernel, dim3(segs), dim3(kSegThreads), kIndexLds, st, d_src, blocks, seg_block, dec, seg_entry, seg_out, seg_last);
         hipLaunchKernelGGL(dec_index_b_kernel, dim3((n + 63) / 64), dim3(64), 0, st, blocks, dec, seg_out, seg_last, seg_entry, n);
         if (segs)
-            hipLaunchKernelGGL(dec_index_c_kernel, dim3(segs), dim3(256), kIndexLds, st, d_src, blocks, seg_block, dec, seg_entry, seg_out, seg_last,
+            hipLaunchKernelGGL(dec_index_c_kernel, dim3(segs), dim3(kSegThreads), kIndexLds, st, d_src, blocks, seg_block, dec, seg_entry, seg_out, seg_last,
                                tile_start, tok_mask);
         if (tiles) hipLaunchKernelGGL(dec_schedule_kernel, dim3(1), dim3(256), 0, st, blocks, tile_block, dec, order, tiles);
     }

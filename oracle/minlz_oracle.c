@@ -567,6 +567,264 @@ size_t mlzo_encode_block_l2(uint8_t* dst, const uint8_t* src, size_t n) {
     return l2_big(dst, src, (long)n);
 }
 
+/*
+ * L3 "Smallest".  encodeBlockBest (encode_l3.go:38-625) without dictionary support (dict is nil
+ * for block encoding, encode.go:101).  Two chained tables (cur | prev<<32): long hash8/20 bits and
+ * short hash4/18 bits; every candidate is scored (encode_l3.go:139-160) and the best of up to
+ * ~20 candidates at s, s+1, s+2 and "at the end of the best match" wins (bestOf, :338-373).
+ */
+typedef struct { long offset, s, length, score; int rep, nextrep; } l3match;
+
+static inline long l3_lit_size(long n) { /* emitLiteralSizeN, encode.go:285-299 */
+    if (n == 0) return 0;
+    if (n <= 29) return 1;
+    if (n < 29 + (1 << 8)) return 2;
+    if (n < 29 + (1 << 16)) return 3;
+    return 4;
+}
+static inline long l3_repeat_size(long length) { /* emitRepeatSize, encode_l3.go:664-680 */
+    if (length <= 0) return 0;
+    if (length <= 29) return 1;
+    length -= 29;
+    if (length <= 256) return 2;
+    if (length <= 65536) return 3;
+    return 4;
+}
+static inline long l3_copy2_size(long length) { /* emitCopy2Size, encode_l3.go:684-699 */
+    length -= 4;
+    if (length <= 60) return 3;
+    length -= 60;
+    if (length < 256) return 4;
+    if (length < 65536) return 5;
+    return 6;
+}
+static inline long bits_len_u(unsigned long v) { long n = 0; while (v) { n++; v >>= 1; } return n; }
+static inline long l3_copy_size(long offset, long length) { /* emitCopySize, encode_l3.go:633-660 */
+    if (offset > 65536 + 63) {
+        length -= 64;
+        if (length <= 0) return 4;
+        return 4 + (bits_len_u((unsigned long)length) + 7) / 8;
+    }
+    if (offset <= 1024) {
+        if (length <= 18) return 2;
+        if (length < 18 + 256) return 3;
+        return 2 + l3_repeat_size(length - 18);
+    }
+    return l3_copy2_size(length);
+}
+static inline uint32_t hash8(uint64_t u, unsigned h) { return (uint32_t)((u * 0xcf1bbcdcb7a56463ull) >> (64 - h)); }
+
+typedef struct { const uint8_t* src; long n, sLimit, nextEmit; const l3match* best; } l3ctx;
+
+static long l3_score(const l3ctx* c, const l3match* m) { /* encode_l3.go:139-160 */
+    long ll = m->s - c->nextEmit;
+    long score = m->length - l3_lit_size(ll) - m->s;
+    long offset = m->s - m->offset;
+    if (m->rep) return score - l3_repeat_size(m->length);
+    if (ll > 0 && offset > 1024) {
+        if (ll <= MAX_COPY2_LITS && offset < 65536 + 63 && m->length <= COPY2_LIT_MAX_LEN) score++;
+        else if (ll <= MAX_COPY3_LITS) score++;
+    }
+    return score - l3_copy_size(offset, m->length);
+}
+
+static l3match l3_extend(const l3ctx* c, long offset, long s, long matched, int rep) {
+    const uint8_t* src = c->src;
+    l3match m = {offset, s, matched + offset, 0, rep, 0};
+    s += matched;
+    while (s < c->n) { /* forward, encode_l3.go:177-191 */
+        if (c->n - s < 8) {
+            if (src[s] == src[m.length]) { m.length++; s++; continue; }
+            break;
+        }
+        uint64_t diff = ld64(src, s) ^ ld64(src, m.length);
+        if (diff) { m.length += ctz64(diff) >> 3; break; }
+        s += 8; m.length += 8;
+    }
+    while (m.s > c->nextEmit && m.offset > 0) { /* backward, :193-200 */
+        if (src[m.offset - 1] != src[m.s - 1]) break;
+        m.s--; m.offset--; m.length++;
+    }
+    m.length -= offset;
+    return m;
+}
+
+static l3match l3_match_at(const l3ctx* c, long offset, long s, uint32_t first) { /* matchAt, :162-215 */
+    l3match none = {offset, s, 0, 0, 0, 0};
+    const l3match* best = c->best;
+    if ((best->length != 0 && best->s - best->offset == s - offset) || s - offset >= MAX_COPY3_OFFSET || s <= offset) return none;
+    if (ld32(c->src, offset) != first) return none;
+    l3match m = l3_extend(c, offset, s, 4, 0);
+    m.score = l3_score(c, &m);
+    if (m.score <= -m.s) m.length = 0;
+    if (m.s + m.length < c->sLimit) {
+        long a = m.s + m.length + 1, b = m.offset + m.length + 1;
+        m.nextrep = ld32(c->src, a) == ld32(c->src, b);
+    }
+    return m;
+}
+
+static l3match l3_match_repeat(const l3ctx* c, long offset, long s, uint32_t first) { /* matchAtRepeat, :216-263 */
+    l3match none = {offset, s, 0, 0, 0, 0};
+    if (c->best->rep) return none;
+    const uint32_t mask = (1u << 24) - 1;
+    if ((ld32(c->src, offset) & mask) != (first & mask)) return none;
+    l3match m = l3_extend(c, offset, s, 3, 1);
+    if (m.s + m.length < c->sLimit) {
+        long a = m.s + m.length + 1, b = m.offset + m.length + 1;
+        m.nextrep = ld32(c->src, a) == ld32(c->src, b);
+    }
+    m.score = l3_score(c, &m);
+    return m;
+}
+
+static l3match l3_best_of(l3match a, l3match b) { /* bestOf, :338-373 */
+    if (b.length == 0) return a;
+    if (a.length == 0) return b;
+    if (a.score > b.score) return a;
+    if (b.score > a.score) return b;
+    if (a.s != b.s) return a.s < b.s ? a : b;
+    if (a.nextrep != b.nextrep) return a.nextrep ? a : b;
+    return a.offset > b.offset ? a : b;
+}
+
+size_t mlzo_encode_block_l3(uint8_t* dst, const uint8_t* src, size_t n_) {
+    const long n = (long)n_;
+    enum { LBITS = 20, SBITS = 18, MAXSKIP = 64 };
+    if (n < MIN_NON_LITERAL_BLOCK_SIZE) return 0;
+    const long sLimit = n - (8 + 2);
+    uint64_t* lTable = (uint64_t*)calloc((size_t)1 << LBITS, 8);
+    uint64_t* sTable = (uint64_t*)calloc((size_t)1 << SBITS, 8);
+    const long dstLimit = n - 5;
+    long nextEmit = 0, s = 1, repeat = 1, d = 0;
+    uint64_t cv = ld64(src, s);
+    size_t ret = 0;
+#define CUR(x) ((long)((x) & 0xffffffffull))
+#define PREV(x) ((long)((x) >> 32))
+    for (;;) {
+        l3match best = {0, 0, 0, 0, 0, 0};
+        l3ctx c = {src, n, sLimit, nextEmit, &best};
+        for (;;) {
+            long nextS = ((s - nextEmit) >> 8) + 1;
+            if (nextS > MAXSKIP) nextS = s + MAXSKIP; else nextS += s;
+            if (nextS > sLimit) goto emit_remainder;
+            const uint32_t hashL = hash8(cv, LBITS), hashS = hash4(cv, SBITS);
+            const uint64_t candidateL = lTable[hashL], candidateS = sTable[hashS];
+            if (s > 0) {
+                best = l3_best_of(l3_match_at(&c, CUR(candidateL), s, (uint32_t)cv), l3_match_at(&c, PREV(candidateL), s, (uint32_t)cv));
+                best = l3_best_of(best, l3_match_at(&c, CUR(candidateS), s, (uint32_t)cv));
+                best = l3_best_of(best, l3_match_at(&c, PREV(candidateS), s, (uint32_t)cv));
+            }
+            best = l3_best_of(best, l3_match_repeat(&c, s - repeat, s, (uint32_t)cv));
+            best = l3_best_of(best, l3_match_repeat(&c, s - repeat + 1, s + 1, (uint32_t)(cv >> 8)));
+            if (best.length > 0) {
+                const uint32_t hS1 = hash4(cv >> 8, SBITS);
+                uint64_t nextShort = sTable[hS1];
+                long sFwd = s + 1;
+                uint64_t cv2 = ld64(src, sFwd);
+                uint64_t nextLong = lTable[hash8(cv2, LBITS)];
+                best = l3_best_of(best, l3_match_at(&c, CUR(nextShort), sFwd, (uint32_t)cv2));
+                best = l3_best_of(best, l3_match_at(&c, PREV(nextShort), sFwd, (uint32_t)cv2));
+                best = l3_best_of(best, l3_match_at(&c, CUR(nextLong), sFwd, (uint32_t)cv2));
+                best = l3_best_of(best, l3_match_at(&c, PREV(nextLong), sFwd, (uint32_t)cv2));
+                /* s + 2 */
+                sFwd++;
+                cv2 = ld64(src, sFwd);
+                nextLong = lTable[hash8(cv2, LBITS)];
+                best = l3_best_of(best, l3_match_repeat(&c, sFwd - repeat, sFwd, (uint32_t)cv2));
+                nextShort = sTable[hash4(cv2, SBITS)];
+                best = l3_best_of(best, l3_match_at(&c, CUR(nextShort), sFwd, (uint32_t)cv2));
+                best = l3_best_of(best, l3_match_at(&c, PREV(nextShort), sFwd, (uint32_t)cv2));
+                best = l3_best_of(best, l3_match_at(&c, CUR(nextLong), sFwd, (uint32_t)cv2));
+                best = l3_best_of(best, l3_match_at(&c, PREV(nextLong), sFwd, (uint32_t)cv2));
+                /* a match found from the end of the best match, allowing 2 mismatching bytes at its start (:466-498) */
+                const long sAt = best.s + best.length - 1;
+                if (sAt < sLimit) {
+                    const long sBack = best.s + 2 - 1, backL = best.length - 2;
+                    cv2 = ld64(src, sBack);
+                    uint64_t next = lTable[hash8(ld64(src, sAt), LBITS)];
+                    long checkAt = CUR(next) - backL;
+                    if (checkAt > 0) best = l3_best_of(best, l3_match_at(&c, checkAt, sBack, (uint32_t)cv2));
+                    checkAt = PREV(next) - backL;
+                    if (checkAt > 0) best = l3_best_of(best, l3_match_at(&c, checkAt, sBack, (uint32_t)cv2));
+                    next = sTable[hash4(ld64(src, sAt), SBITS)];
+                    checkAt = CUR(next) - backL;
+                    if (checkAt > 0) best = l3_best_of(best, l3_match_at(&c, checkAt, sBack, (uint32_t)cv2));
+                    checkAt = PREV(next) - backL;
+                    if (checkAt > 0) best = l3_best_of(best, l3_match_at(&c, checkAt, sBack, (uint32_t)cv2));
+                }
+            }
+            lTable[hashL] = (uint64_t)s | candidateL << 32;
+            sTable[hashS] = (uint64_t)s | candidateS << 32;
+            if (best.length > 0) break;
+            cv = ld64(src, nextS);
+            s = nextS;
+        }
+        const long startIdx = s + 1;
+        s = best.s;
+        if (d + (s - nextEmit) > dstLimit) goto done;
+        const long base = s, offset = s - best.offset;
+        s += best.length;
+        if (!best.rep && best.length <= 4) { /* not worth it, :514-526 */
+            if (offset > 65535 || (offset > MAX_COPY1_OFFSET && offset <= MAX_COPY2_OFFSET && base - nextEmit > MAX_COPY2_LITS)) {
+                s = startIdx + 1;
+                if (s >= sLimit) goto emit_remainder;
+                cv = ld64(src, s);
+                continue;
+            }
+        }
+        const long nl = base - nextEmit;
+        if (best.rep) {
+            d += mlzo_emit_literal(dst + d, src + nextEmit, nl);
+            d += mlzo_emit_repeat(dst + d, best.length);
+        } else if (nl > 0) {
+            if (offset <= MAX_COPY2_OFFSET) {
+                if (nl > MAX_COPY2_LITS || offset < 64 || (offset <= 1024 && best.length > COPY2_LIT_MAX_LEN)) {
+                    d += mlzo_emit_literal(dst + d, src + nextEmit, nl);
+                    if (best.length > 18 && best.length <= 64 && offset >= 64) d += encode_copy2(dst + d, offset, best.length);
+                    else d += mlzo_emit_copy(dst + d, offset, best.length);
+                } else if (best.length > 11) { /* the rest is searched again rather than emitted as a repeat */
+                    d += mlzo_emit_copy_lits2(dst + d, src + nextEmit, nl, offset, 11);
+                    s = best.s + 11;
+                } else {
+                    d += mlzo_emit_copy_lits2(dst + d, src + nextEmit, nl, offset, best.length);
+                }
+            } else if (nl > MAX_COPY3_LITS) {
+                d += mlzo_emit_literal(dst + d, src + nextEmit, nl);
+                d += mlzo_emit_copy(dst + d, offset, best.length);
+            } else {
+                d += mlzo_emit_copy_lits3(dst + d, src + nextEmit, nl, offset, best.length);
+            }
+        } else {
+            if (best.length > 18 && best.length <= 64 && offset >= 64 && offset <= MAX_COPY2_OFFSET) d += encode_copy2(dst + d, offset, best.length);
+            else d += mlzo_emit_copy(dst + d, offset, best.length);
+        }
+        repeat = offset;
+        nextEmit = s;
+        if (s >= sLimit) goto emit_remainder;
+        if (d > dstLimit) goto done;
+        for (long i = startIdx; i < s; i++) { /* fill tables, :606-612 */
+            const uint64_t cv0 = ld64(src, i);
+            const uint32_t l0 = hash8(cv0, LBITS), s0 = hash4(cv0, SBITS);
+            lTable[l0] = (uint64_t)i | lTable[l0] << 32;
+            sTable[s0] = (uint64_t)i | sTable[s0] << 32;
+        }
+        cv = ld64(src, s);
+    }
+emit_remainder:
+    if (nextEmit < n) {
+        const long litLen = n - nextEmit;
+        if (d + litLen + l3_lit_size(litLen) > dstLimit) goto done;
+        d += mlzo_emit_literal(dst + d, src + nextEmit, litLen);
+    }
+    ret = (size_t)d;
+done:
+    free(lTable); free(sTable);
+    return ret;
+#undef CUR
+#undef PREV
+}
+
 /* encodeUncompressed, encode.go:223-228 */
 static long encode_uncompressed(uint8_t* dst, const uint8_t* src, size_t n) {
     if (n == 0) { dst[0] = 0; return 1; }
@@ -574,8 +832,8 @@ static long encode_uncompressed(uint8_t* dst, const uint8_t* src, size_t n) {
     return (long)n + 2;
 }
 
-/* Encode, encode.go:74-139.  Levels: 0 uncompressed, 1 fastest, 2 balanced.
- * (LevelSuperFast -1 and LevelSmallest 3 are not restated: SURVEY.md section 2 rows 6-7.) */
+/* Encode, encode.go:74-139.  Levels: 0 uncompressed, 1 fastest, 2 balanced, 3 smallest.
+ * (LevelSuperFast -1 is not restated: SURVEY.md section 2 row 7.) */
 long mlzo_encode(uint8_t* dst, size_t dcap, const uint8_t* src, size_t n, int level) {
     long maxlen = mlzo_max_encoded_len(n);
     if (maxlen < 0) return -MLZO_ERR_TOO_LARGE;
@@ -588,6 +846,7 @@ long mlzo_encode(uint8_t* dst, size_t dcap, const uint8_t* src, size_t n, int le
     case 0: return encode_uncompressed(dst, src, n);
     case 1: m = mlzo_encode_block_l1(dst + d, src, n); break;
     case 2: m = mlzo_encode_block_l2(dst + d, src, n); break;
+    case 3: m = mlzo_encode_block_l3(dst + d, src, n); break;
     default: return -MLZO_ERR_INVALID_LEVEL;
     }
     if (m > 0) return (long)(d + m);
@@ -655,6 +914,7 @@ long mlzo_stream_encode(uint8_t* dst, size_t dcap, const uint8_t* src, size_t n,
         case 0: n2 = 0; break;
         case 1: n2 = mlzo_encode_block_l1(ob + 8 + vn, u, bl); break;
         case 2: n2 = mlzo_encode_block_l2(ob + 8 + vn, u, bl); break;
+        case 3: n2 = mlzo_encode_block_l3(ob + 8 + vn, u, bl); break;
         default: return -MLZO_ERR_INVALID_LEVEL;
         }
         size_t chunk_len; uint8_t type;

@@ -6,12 +6,14 @@
  * minio/minlz tree).  It is NOT part of the product: only tests/, __graft_entry__.smoke() and
  * bench.py's cpu_baseline leg may load it.  The product path (minlz_amd/) never links it.
  *
- * Pinning status (see oracle/README.md):
+ * Pinning status:
  *   decode  : pinned — bit-exact on testdata/Mark.Twain-Tom.Sawyer.txt.mzb -> .txt
  *             (minlz_test.go:626-660) and on the negative set fuzz/block-corpus-dec.zip.
  *   emitters: pinned — TestEmitLiteral / TestEmitCopy byte tables (minlz_test.go:871-1026).
  *   crc     : pinned — framing KAT crc("abcd") -> 68 10 e6 b6 (minlz_test.go:1120-1134).
- *   encoders: "parity unpinned" byte-wise (no Go toolchain here, no reference-encoded L1/L2
+ *   L3 enc  : pinned — mlzo_encode(.txt, 3) is byte-identical to the reference's committed
+ *             testdata/Mark.Twain-Tom.Sawyer.txt.mzb (8875 bytes).
+ *   L1/L2   : "parity unpinned" byte-wise (no Go toolchain here, no reference-encoded L1/L2
  *             artefacts in the tree); pinned only through round-trip against the pinned decoder
  *             and the reference's ratio assertion (minlz_test.go:780-797).
  */
@@ -62,6 +64,8 @@ long mlzo_max_encoded_len(size_t n);
 /* encodeBlock / encodeBlockBetter (asm_none.go:51-76): token stream only, 0 = incompressible. */
 size_t mlzo_encode_block_l1(uint8_t* dst, const uint8_t* src, size_t n);
 size_t mlzo_encode_block_l2(uint8_t* dst, const uint8_t* src, size_t n);
+/* encodeBlockBest (encode_l3.go:38-625), no dictionary. */
+size_t mlzo_encode_block_l3(uint8_t* dst, const uint8_t* src, size_t n);
 /* Encode (encode.go:74-139): full block with header. Returns bytes written, <0 = -MLZO_ERR_*. */
 long mlzo_encode(uint8_t* dst, size_t dcap, const uint8_t* src, size_t n, int level);
 

@@ -49,6 +49,7 @@ def lib():
         L.mlzo_max_encoded_len.argtypes = [sz]; L.mlzo_max_encoded_len.restype = C.c_long
         L.mlzo_encode_block_l1.argtypes = [u8p, u8p, sz]; L.mlzo_encode_block_l1.restype = sz
         L.mlzo_encode_block_l2.argtypes = [u8p, u8p, sz]; L.mlzo_encode_block_l2.restype = sz
+        L.mlzo_encode_block_l3.argtypes = [u8p, u8p, sz]; L.mlzo_encode_block_l3.restype = sz
         L.mlzo_encode.argtypes = [u8p, sz, u8p, sz, C.c_int]; L.mlzo_encode.restype = C.c_long
         L.mlzo_crc.argtypes = [u8p, sz]; L.mlzo_crc.restype = C.c_uint32
         L.mlzo_stream_bound.argtypes = [sz, sz]; L.mlzo_stream_bound.restype = sz
@@ -119,7 +120,7 @@ def encode_block(src, level=1):
     """encodeBlock / encodeBlockBetter: token stream only; b'' = incompressible."""
     a, p, n = _buf(src)
     out = np.empty(n + 64, dtype=np.uint8)
-    f = lib().mlzo_encode_block_l1 if level == 1 else lib().mlzo_encode_block_l2
+    f = {1: lib().mlzo_encode_block_l1, 2: lib().mlzo_encode_block_l2, 3: lib().mlzo_encode_block_l3}[level]
     r = f(out.ctypes.data, p, n)
     return out[:r].tobytes()
 

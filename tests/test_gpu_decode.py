@@ -57,7 +57,7 @@ def test_negative_corpus_same_verdict_as_oracle(ctx):
     assert n > 500
 
 
-@pytest.mark.parametrize("level", [1, 2])
+@pytest.mark.parametrize("level", [1, 2, 3])
 def test_oracle_encoded_regressions(ctx, level):
     # reference-algorithm streams (arbitrary cross-tile references) must decode bit-exact
     for label, blob in load_zip("enc_regressions.zip"):
@@ -149,6 +149,24 @@ def test_full_size_blocks(ctx):
         d = gen()
         for level in (1, 2):
             assert mz.Decode(O.encode(d, level), ctx) == d.tobytes()
+
+
+def test_config5_smallest_64k_blocks(ctx):
+    # BASELINE.json configs[4]: LevelSmallest at 64 KiB blocks — CPU (oracle L3) encode, device
+    # decode of the whole batch in one launch, and the ratio ordering L3 <= L2 <= L1.
+    bs = 64 << 10
+    d = synth.text_like(16 << 20, 21)
+    blocks = [d[i:i + bs].tobytes() for i in range(0, d.size, bs)]
+    enc = {lv: [O.encode(b, lv) for b in blocks] for lv in (1, 2, 3)}
+    tot = {lv: sum(map(len, enc[lv])) for lv in enc}
+    assert tot[3] <= tot[2] <= tot[1] < d.size
+    for lv in (3, 2):
+        assert mz.decode_batch(enc[lv], ctx) == blocks
+    # the device encoder at this block size still beats "stored" and decodes with the oracle
+    gpu = mz.encode_batch(blocks, 1, ctx)
+    assert sum(map(len, gpu)) < 0.6 * d.size
+    for g, b in zip(gpu[::17], blocks[::17]):
+        assert O.decode(g) == b
 
 
 def test_serial_and_parallel_agree(ctx):

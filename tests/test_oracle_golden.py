@@ -16,6 +16,14 @@ def test_tom_sawyer_golden_decode(twain, twain_mzb):
     assert O.decode(twain_mzb, guard=64) == twain
 
 
+def test_tom_sawyer_golden_encode_l3(twain, twain_mzb):
+    # The reference's committed testdata/Mark.Twain-Tom.Sawyer.txt.mzb (minlz_test.go:626-660) is
+    # byte-identical to Encode(nil, txt, LevelSmallest) as restated here: this pins the L3 encoder
+    # restatement (encode_l3.go:38-625) — match search, scoring, tie-breaks and emitters — on a
+    # reference-produced artefact.
+    assert O.encode(twain, 3) == twain_mzb
+
+
 def test_emit_literal_kat(golden):
     kat = json.load(open(os.path.join(golden, "emit_kat.json")))
     assert len(kat["emit_literal"]) == 18

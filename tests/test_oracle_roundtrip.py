@@ -8,7 +8,7 @@ from minlz_amd import synth
 from tests.util import load_zip
 
 
-@pytest.mark.parametrize("level", [1, 2])
+@pytest.mark.parametrize("level", [1, 2, 3])
 def test_enc_regressions_roundtrip(level):
     # testdata/enc_regressions.zip (decode_asm_test.go:49-73, writer_test.go:31-72)
     items = load_zip("enc_regressions.zip")
@@ -82,6 +82,29 @@ def test_too_large():
 
 
 def test_level_ordering_on_text():
-    d = synth.text_like(1 << 20, 5)
-    l1, l2 = len(O.encode(d, 1)), len(O.encode(d, 2))
-    assert l2 <= l1 < d.size
+    # BASELINE config 5: L3 <= L2 <= L1 (README.md:318-330 ratio table ordering)
+    for d in (synth.text_like(1 << 20, 5), synth.json_like(1 << 20)):
+        l1, l2, l3 = (len(O.encode(d, lv)) for lv in (1, 2, 3))
+        assert l3 <= l2 <= l1 < d.size
+
+
+def test_l3_roundtrip_shapes():
+    for name in synth.PATTERNS:
+        d = synth.pattern(name, 200000)
+        assert O.decode(O.encode(d, 3)) == d.tobytes(), name
+    for n in (0, 1, 15, 16, 17, 31, 64, 65, 1000, 65536, 65537):
+        d = synth.text_like(1 << 17, 3)[:n]
+        assert O.decode(O.encode(d, 3)) == d.tobytes(), n
+    d = synth.random_bytes(100000)
+    e = O.encode(d, 3)
+    assert e[:2] == b"\x00\x00" and O.decode(e) == d.tobytes()
+    d = synth.large_offset(3 << 20, 1 << 20)
+    assert O.decode(O.encode(d, 3)) == d.tobytes()
+
+
+def test_l3_stream_64k_blocks():
+    # config 5 shape: LevelSmallest at 64 KiB block size through the framed stream
+    d = synth.text_like(1 << 20, 9)
+    st = O.stream_encode(d, 3, 64 << 10)
+    assert O.stream_decode(st, d.size) == d.tobytes()
+    assert len(st) <= len(O.stream_encode(d, 2, 64 << 10))

@@ -40,7 +40,7 @@ def main():
     ap.add_argument("--bytes", type=int, default=100_000_000, help="uncompressed stream bytes per GPU (enwik8 = 1e8)")
     ap.add_argument("--level", type=int, default=1)
     ap.add_argument("--far", type=int, default=1)
-    ap.add_argument("--staged", type=int, default=-1, help="encoder tile bytes in LDS (1) or in place (0); -1 = library default")
+    ap.add_argument("--staged", type=int, default=-1, help="encoder variant: 0 in-place (default), 1 LDS-staged, 3 software-pipelined; -1 = library default")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--workload", default="text", choices=["text", "json", "random"])
     args = ap.parse_args()

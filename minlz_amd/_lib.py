@@ -6,7 +6,8 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SO = os.path.join(HERE, "libminlz_hip.so")
+# MINLZ_HIP_LIB: development override used by tools/ to time experimental builds of the same library
+SO = os.environ.get("MINLZ_HIP_LIB") or os.path.join(HERE, "libminlz_hip.so")
 
 # every symbol include/minlz_hip.h declares (checked by tests/test_abi.py)
 SYMBOLS = [

@@ -17,8 +17,10 @@
 #include "mlz_kernels.h"
 
 #include "mlz_encode.hip.inc"
+#include "mlz_encode_pipe.hip.inc"
 #include "mlz_decode_serial.hip.inc"
 #include "mlz_decode.hip.inc"
+#include "mlz_decode_exec.hip.inc"
 #include "mlz_crc.hip.inc"
 
 using namespace mlz;
@@ -40,6 +42,9 @@ struct DevBuf {
     template <class T> T* as() { return static_cast<T*>(p); }
 };
 
+constexpr size_t kProfTiles = 4096;                      // debug timeline: tiles recorded by the exec pass
+constexpr size_t kProfBytes = 256 + kProfTiles * 32;
+
 enum { T_FAR = 0, T_ENC_TILES, T_ENC_LAYOUT, T_ENC_GATHER, T_DEC_PARSE, T_DEC_CHAIN, T_DEC_INDEX, T_DEC_EXEC, T_DEC_SERIAL, T_CRC, T_COUNT };
 const char* kTimerNames[T_COUNT] = {"enc_far_build", "enc_tiles", "enc_layout", "enc_gather", "dec_parse", "dec_chain", "dec_index", "dec_exec", "dec_serial", "crc"};
 
@@ -60,7 +65,7 @@ struct mlz_ctx {
     hipEvent_t upload_done = nullptr;
     bool upload_pending = false;
     // encode workspace
-    DevBuf d_scratch, d_tile_size, d_tile_out, d_flags, d_far;
+    DevBuf d_scratch, d_tile_size, d_tile_out, d_flags, d_far, d_dummy;
     // decode workspace
     DevBuf d_dec;
     // host-pointer staging
@@ -198,8 +203,19 @@ int encode_device_locked(mlz_ctx* c, hipStream_t st, int level, const uint8_t* d
 #define MLZ_LAUNCH_ENC(F, S, LDS)                                                                                                         \
     hipLaunchKernelGGL((encode_tiles_kernel<F, S>), dim3(tiles), dim3(64), LDS, st, d_src, blocks, tile_block, c->d_scratch.as<uint8_t>(), \
                        c->d_tile_size.as<uint32_t>(), ftab, epochs, prof)
-            if (c->encode_staged) { if (far) MLZ_LAUNCH_ENC(true, true, kEncLdsStaged); else MLZ_LAUNCH_ENC(false, true, kEncLdsStaged); }
-            else { if (far) MLZ_LAUNCH_ENC(true, false, kEncLdsInPlace); else MLZ_LAUNCH_ENC(false, false, kEncLdsInPlace); }
+            if (c->encode_staged == 1) { if (far) MLZ_LAUNCH_ENC(true, true, kEncLdsStaged); else MLZ_LAUNCH_ENC(false, true, kEncLdsStaged); }
+            else if (c->encode_staged != 3) { if (far) MLZ_LAUNCH_ENC(true, false, kEncLdsInPlace); else MLZ_LAUNCH_ENC(false, false, kEncLdsInPlace); }
+            else {  // experiment: software-pipelined kernel (mlz_encode_pipe.hip.inc); same speed, see DESIGN.md section 6
+                if (!c->d_dummy.p) {
+                    HIPCHK(c, c->d_dummy.ensure(256));
+                    HIPCHK(c, hipMemsetAsync(c->d_dummy.p, 0, 256, st));
+                }
+                const uint8_t* dummy = c->d_dummy.as<uint8_t>();
+                if (far) hipLaunchKernelGGL((encode_tiles_pipe_kernel<true>), dim3(tiles), dim3(64), kEncLdsInPlace, st, d_src, blocks, tile_block,
+                                            c->d_scratch.as<uint8_t>(), c->d_tile_size.as<uint32_t>(), ftab, epochs, dummy, prof);
+                else hipLaunchKernelGGL((encode_tiles_pipe_kernel<false>), dim3(tiles), dim3(64), kEncLdsInPlace, st, d_src, blocks, tile_block,
+                                        c->d_scratch.as<uint8_t>(), c->d_tile_size.as<uint32_t>(), ftab, epochs, dummy, prof);
+            }
 #undef MLZ_LAUNCH_ENC
         }
     }
@@ -231,7 +247,9 @@ int decode_parallel(mlz_ctx* c, hipStream_t st, const uint8_t* d_src, uint8_t* d
     const size_t o_slast = o_sout + al(size_t(segs) * 4);
     const size_t o_tstart = o_slast + al(size_t(segs) * 4);
     const size_t o_mask = o_tstart + al(size_t(tiles) * sizeof(TileStart));
-    const size_t o_order = o_mask + al(size_t(segs) * kSegThreads * 8);
+    const size_t o_cd = o_mask + al(size_t(segs) * kSegThreads * 8);
+    const size_t o_cr = o_cd + al(size_t(segs) * kSegThreads * 4);
+    const size_t o_order = o_cr + al(size_t(segs) * kSegThreads * 4);
     const size_t o_done = o_order + al(size_t(tiles) * 4);
     const size_t o_ticket = o_done + al(size_t(tiles) * 4);
     const size_t total = o_ticket + 256;
@@ -244,6 +262,8 @@ int decode_parallel(mlz_ctx* c, hipStream_t st, const uint8_t* d_src, uint8_t* d
     uint32_t* seg_last = reinterpret_cast<uint32_t*>(ws + o_slast);
     TileStart* tile_start = reinterpret_cast<TileStart*>(ws + o_tstart);
     uint64_t* tok_mask = reinterpret_cast<uint64_t*>(ws + o_mask);
+    uint32_t* chunk_d = reinterpret_cast<uint32_t*>(ws + o_cd);
+    uint32_t* chunk_rep = reinterpret_cast<uint32_t*>(ws + o_cr);
     uint32_t* order = reinterpret_cast<uint32_t*>(ws + o_order);
     uint32_t* tile_done = reinterpret_cast<uint32_t*>(ws + o_done);
     uint32_t* ticket = reinterpret_cast<uint32_t*>(ws + o_ticket);
@@ -256,6 +276,7 @@ int decode_parallel(mlz_ctx* c, hipStream_t st, const uint8_t* d_src, uint8_t* d
         HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(dec_index_a_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kIndexLds));
         HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(dec_index_c_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kIndexLds));
         HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(dec_exec_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kTile));
+        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(dec_exec2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kExecLds));
         attrs = true;
     }
     {
@@ -277,14 +298,18 @@ int decode_parallel(mlz_ctx* c, hipStream_t st, const uint8_t* d_src, uint8_t* d
         hipLaunchKernelGGL(dec_index_b_kernel, dim3((n + 63) / 64), dim3(64), 0, st, blocks, dec, seg_out, seg_last, seg_entry, n);
         if (segs)
             hipLaunchKernelGGL(dec_index_c_kernel, dim3(segs), dim3(kSegThreads), kIndexLds, st, d_src, blocks, seg_block, dec, seg_entry, seg_out, seg_last,
-                               tile_start, tok_mask);
+                               tile_start, tok_mask, chunk_d, chunk_rep);
         if (tiles) hipLaunchKernelGGL(dec_schedule_kernel, dim3(1), dim3(256), 0, st, blocks, tile_block, dec, order, tiles);
     }
     {
         Timer t(c, T_DEC_EXEC, st);
-        if (tiles)
+        unsigned long long* prof = c->prof_on ? c->d_prof.as<unsigned long long>() : nullptr;
+        if (tiles && c->decode_algo == 2)  // previous exec pass: one wave per tile, single phase
             hipLaunchKernelGGL(dec_exec_kernel, dim3(tiles), dim3(64), kTile, st, d_src, d_dst, blocks, tile_block, dec, tile_start, tok_mask, order, tile_done, ticket,
-                               tiles, c->prof_on ? c->d_prof.as<unsigned long long>() : nullptr);
+                               tiles, prof);
+        else if (tiles)
+            hipLaunchKernelGGL(dec_exec2_kernel, dim3(tiles), dim3(kExecThreads), kExecLds, st, d_src, d_dst, blocks, tile_block, dec, tile_start, tok_mask,
+                               chunk_d, chunk_rep, order, tile_done, ticket, tiles, prof);
         hipLaunchKernelGGL(dec_finish_kernel, dim3((n + 63) / 64), dim3(64), 0, st, dec, d_out_len, n, c->debug_status);
     }
     HIPCHK(c, hipGetLastError());
@@ -401,7 +426,7 @@ void mlz_destroy(mlz_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
-    for (DevBuf* b : {&c->d_crc, &c->d_prof, &c->d_blocks, &c->d_tile_block, &c->d_seg_block, &c->d_scratch, &c->d_tile_size, &c->d_tile_out, &c->d_flags, &c->d_far, &c->d_dec, &c->d_in, &c->d_out, &c->d_len})
+    for (DevBuf* b : {&c->d_crc, &c->d_prof, &c->d_blocks, &c->d_tile_block, &c->d_seg_block, &c->d_scratch, &c->d_tile_size, &c->d_tile_out, &c->d_flags, &c->d_far, &c->d_dummy, &c->d_dec, &c->d_in, &c->d_out, &c->d_len})
         b->release();
     if (c->pinned) (void)hipHostFree(c->pinned);
     for (int i = 0; i < T_COUNT; i++)
@@ -520,17 +545,23 @@ int mlz_set_option(mlz_ctx* c, int opt, int64_t value) {
     switch (opt) {
     case MLZ_OPT_DECODE_ALGO: c->decode_algo = int(value); return 0;
     case MLZ_OPT_ENCODE_FAR: c->encode_far = int(value); return 0;
-    case 6: c->encode_staged = int(value); return 0;  // tuning: stage tile bytes in LDS (1) or read them in place (0)
+    case 6: c->encode_staged = int(value); return 0;  // tuning: 0 = in-place tile bytes (default), 1 = LDS-staged tile bytes, 3 = software-pipelined variant
     case 3: c->debug_status = int(value); return 0;  // debug: report failure sites in the error code
     case 4: {  // debug: per-phase cycle counters (16 x u64: 0-7 encode, 8-15 decode)
         c->prof_on = value != 0;
-        if (c->prof_on) { if (c->d_prof.ensure(256) != hipSuccess) return -MLZ_ERR_HIP; if (hipMemset(c->d_prof.p, 0, 256) != hipSuccess) return -MLZ_ERR_HIP; }
+        if (c->prof_on) { if (c->d_prof.ensure(kProfBytes) != hipSuccess) return -MLZ_ERR_HIP; if (hipMemset(c->d_prof.p, 0, kProfBytes) != hipSuccess) return -MLZ_ERR_HIP; }
         return 0;
     }
     case 5: {  // debug: read the counters back into a host buffer whose address is `value`
         if (!c->d_prof.p) return -MLZ_ERR_ARG;
         if (hipDeviceSynchronize() != hipSuccess) return -MLZ_ERR_HIP;
         if (hipMemcpy(reinterpret_cast<void*>(value), c->d_prof.p, 128, hipMemcpyDeviceToHost) != hipSuccess) return -MLZ_ERR_HIP;
+        return 0;
+    }
+    case 7: {  // debug: read the exec pass's per-tile timeline (kProfTiles x 4 u64, 100 MHz clock) into a host buffer
+        if (!c->d_prof.p) return -MLZ_ERR_ARG;
+        if (hipDeviceSynchronize() != hipSuccess) return -MLZ_ERR_HIP;
+        if (hipMemcpy(reinterpret_cast<void*>(value), c->d_prof.as<uint8_t>() + 256, kProfBytes - 256, hipMemcpyDeviceToHost) != hipSuccess) return -MLZ_ERR_HIP;
         return 0;
     }
     case MLZ_TIMER_ENABLE: c->timing = value != 0; for (bool& u : c->ev_used) u = false; return 0;

@@ -1,0 +1,41 @@
+"""Per-tile timeline of the exec pass (debug option 7): start / ready / loop end / published, by level."""
+import os, sys, ctypes as C
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np, torch
+import minlz_amd as mz
+from minlz_amd import synth
+from minlz_amd._lib import BlockDesc
+S = 100_000_000; BLOCK = 8 << 20
+ctx = mz.Context(0)
+host = synth.text_like(S, 1); dev = torch.device("cuda", 0)
+src = torch.from_numpy(host).to(dev); nblk = (S + BLOCK - 1) // BLOCK; stride = BLOCK + 256
+enc = torch.empty(nblk * stride, dtype=torch.uint8, device=dev); enc_len = torch.zeros(nblk, dtype=torch.int64, device=dev)
+blk_len = [min(BLOCK, S - i * BLOCK) for i in range(nblk)]
+desc = (BlockDesc * nblk)(*[BlockDesc(i * BLOCK, blk_len[i], i * stride, stride) for i in range(nblk)])
+st = torch.cuda.current_stream(dev).cuda_stream
+ctx.encode_batch_device(st, 1, src.data_ptr(), enc.data_ptr(), desc, enc_len.data_ptr()); torch.cuda.synchronize()
+lens = enc_len.cpu().tolist()
+dec = torch.empty(S + 256, dtype=torch.uint8, device=dev); dec_len = torch.zeros(nblk, dtype=torch.int64, device=dev)
+ddesc = (BlockDesc * nblk)(*[BlockDesc(i * stride, lens[i], i * BLOCK, blk_len[i]) for i in range(nblk)])
+for _ in range(3):
+    ctx.decode_batch_device(st, enc.data_ptr(), dec.data_ptr(), ddesc, dec_len.data_ptr()); torch.cuda.synchronize()
+ctx.set_option(4, 1)
+ctx.decode_batch_device(st, enc.data_ptr(), dec.data_ptr(), ddesc, dec_len.data_ptr()); torch.cuda.synchronize()
+buf = np.zeros(4096 * 4, dtype=np.uint64)
+ctx.set_option(7, buf.ctypes.data)
+t = buf.reshape(-1, 4)
+ntiles = sum((l + (32 << 10) - 1) // (32 << 10) for l in blk_len)
+t = t[:ntiles]
+lvl = (t[:, 3] >> np.uint64(60)).astype(int)
+tt = t.copy(); tt[:, 3] &= np.uint64((1 << 60) - 1)
+t0 = tt[:, 0].min()
+us = (tt - t0).astype(np.float64) / 100.0  # 100 MHz -> microseconds
+print("tiles", ntiles, "span %.0f us" % us[:, 3].max())
+for L in range(4):
+    m = lvl == L
+    if not m.any(): continue
+    u = us[m]
+    print("level %d n=%d  start %.0f..%.0f  ready %.0f..%.0f (median %.0f)  loopend median %.0f  end %.0f..%.0f | wait med %.0f  loop med %.0f p90 %.0f max %.0f  flush med %.0f" % (
+        L, m.sum(), u[:, 0].min(), u[:, 0].max(), u[:, 1].min(), u[:, 1].max(), np.median(u[:, 1]), np.median(u[:, 2]), u[:, 3].min(), u[:, 3].max(),
+        np.median(u[:, 1] - u[:, 0]), np.median(u[:, 2] - u[:, 1]), np.percentile(u[:, 2] - u[:, 1], 90), (u[:, 2] - u[:, 1]).max(), np.median(u[:, 3] - u[:, 2])))

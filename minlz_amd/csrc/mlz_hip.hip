@@ -242,7 +242,8 @@ int decode_parallel(mlz_ctx* c, hipStream_t st, const uint8_t* d_src, uint8_t* d
     auto al = [](size_t x) { return (x + 255) & ~size_t(255); };
     const size_t o_dec = 0;
     const size_t o_exit = o_dec + al(sizeof(DecBlock) * n);
-    const size_t o_entry = o_exit + al(size_t(segs) * kSeg * 4);
+    const size_t o_rexit = o_exit + al(size_t(segs) * kSeg * 4);
+    const size_t o_entry = o_rexit + al(size_t(segs) * kSeg * 2);
     const size_t o_sout = o_entry + al(size_t(segs) * 4);
     const size_t o_slast = o_sout + al(size_t(segs) * 4);
     const size_t o_tstart = o_slast + al(size_t(segs) * 4);
@@ -257,6 +258,7 @@ int decode_parallel(mlz_ctx* c, hipStream_t st, const uint8_t* d_src, uint8_t* d
     uint8_t* ws = c->d_dec.as<uint8_t>();
     DecBlock* dec = reinterpret_cast<DecBlock*>(ws + o_dec);
     uint32_t* exit_tab = reinterpret_cast<uint32_t*>(ws + o_exit);
+    uint16_t* rexit_tab = reinterpret_cast<uint16_t*>(ws + o_rexit);
     uint32_t* seg_entry = reinterpret_cast<uint32_t*>(ws + o_entry);
     uint32_t* seg_out = reinterpret_cast<uint32_t*>(ws + o_sout);
     uint32_t* seg_last = reinterpret_cast<uint32_t*>(ws + o_slast);
@@ -285,7 +287,7 @@ int decode_parallel(mlz_ctx* c, hipStream_t st, const uint8_t* d_src, uint8_t* d
         HIPCHK(c, hipMemsetAsync(ws + o_done, 0, o_ticket + 256 - o_done, st));
         hipLaunchKernelGGL(dec_header_kernel, dim3((n + 63) / 64), dim3(64), 0, st, d_src, blocks, dec, n, raw_body ? 1 : 0);
         if (segs)
-            hipLaunchKernelGGL(dec_exit_kernel, dim3(segs), dim3(kSegThreads), kExitLds, st, d_src, blocks, seg_block, dec, exit_tab);
+            hipLaunchKernelGGL(dec_exit_kernel, dim3(segs), dim3(kSegThreads), kExitLds, st, d_src, blocks, seg_block, dec, exit_tab, rexit_tab);
     }
     {
         Timer t(c, T_DEC_CHAIN, st);
@@ -294,11 +296,11 @@ int decode_parallel(mlz_ctx* c, hipStream_t st, const uint8_t* d_src, uint8_t* d
     {
         Timer t(c, T_DEC_INDEX, st);
         if (segs)
-            hipLaunchKernelGGL(dec_index_a_kernel, dim3(segs), dim3(kSegThreads), kIndexLds, st, d_src, blocks, seg_block, dec, seg_entry, seg_out, seg_last);
+            hipLaunchKernelGGL(dec_index_a_kernel, dim3(segs), dim3(kSegThreads), kIndexLds, st, d_src, blocks, seg_block, dec, seg_entry, seg_out, seg_last, rexit_tab);
         hipLaunchKernelGGL(dec_index_b_kernel, dim3((n + 63) / 64), dim3(64), 0, st, blocks, dec, seg_out, seg_last, seg_entry, n);
         if (segs)
             hipLaunchKernelGGL(dec_index_c_kernel, dim3(segs), dim3(kSegThreads), kIndexLds, st, d_src, blocks, seg_block, dec, seg_entry, seg_out, seg_last,
-                               tile_start, tok_mask, chunk_d, chunk_rep);
+                               tile_start, tok_mask, chunk_d, chunk_rep, rexit_tab);
         if (tiles) hipLaunchKernelGGL(dec_schedule_kernel, dim3(1), dim3(256), 0, st, blocks, tile_block, dec, order, tiles);
     }
     {

@@ -18,6 +18,7 @@
 
 #include "mlz_encode.hip.inc"
 #include "mlz_encode_pipe.hip.inc"
+#include "mlz_encode_pc.hip.inc"
 #include "mlz_decode_serial.hip.inc"
 #include "mlz_decode.hip.inc"
 #include "mlz_decode_exec.hip.inc"
@@ -193,8 +194,9 @@ int encode_device_locked(mlz_ctx* c, hipStream_t st, int level, const uint8_t* d
                 HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(far_build_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 4u << kFarSliceBits));
                 far_attr = true;
             }
-            hipLaunchKernelGGL(far_build_kernel, dim3(kFarSlices, (kLevels - 1) * epochs, n), dim3(1024), 4u << kFarSliceBits, st, d_src, blocks,
-                               c->d_far.as<uint32_t>(), epochs);
+            for (uint32_t lset = 0; lset + 1 < uint32_t(kLevels); lset++)  // level set L builds on level set L-1
+                hipLaunchKernelGGL(far_build_kernel, dim3(kFarSlices, epochs, n), dim3(1024), 4u << kFarSliceBits, st, d_src, blocks,
+                                   c->d_far.as<uint32_t>(), epochs, lset);
         }
         {
             Timer t(c, T_ENC_TILES, st);
@@ -204,6 +206,17 @@ int encode_device_locked(mlz_ctx* c, hipStream_t st, int level, const uint8_t* d
     hipLaunchKernelGGL((encode_tiles_kernel<F, S>), dim3(tiles), dim3(64), LDS, st, d_src, blocks, tile_block, c->d_scratch.as<uint8_t>(), \
                        c->d_tile_size.as<uint32_t>(), ftab, epochs, prof)
             if (c->encode_staged == 1) { if (far) MLZ_LAUNCH_ENC(true, true, kEncLdsStaged); else MLZ_LAUNCH_ENC(false, true, kEncLdsStaged); }
+            else if (c->encode_staged == 4) {  // experiment: producer/consumer pair of waves per tile (mlz_encode_pc.hip.inc)
+                if (!c->d_dummy.p) {
+                    HIPCHK(c, c->d_dummy.ensure(256));
+                    HIPCHK(c, hipMemsetAsync(c->d_dummy.p, 0, 256, st));
+                }
+                const uint8_t* dummy = c->d_dummy.as<uint8_t>();
+                if (far) hipLaunchKernelGGL((encode_tiles_pc_kernel<true>), dim3(tiles), dim3(128), kEncLdsPc, st, d_src, blocks, tile_block,
+                                            c->d_scratch.as<uint8_t>(), c->d_tile_size.as<uint32_t>(), ftab, epochs, dummy, prof);
+                else hipLaunchKernelGGL((encode_tiles_pc_kernel<false>), dim3(tiles), dim3(128), kEncLdsPc, st, d_src, blocks, tile_block,
+                                        c->d_scratch.as<uint8_t>(), c->d_tile_size.as<uint32_t>(), ftab, epochs, dummy, prof);
+            }
             else if (c->encode_staged != 3) { if (far) MLZ_LAUNCH_ENC(true, false, kEncLdsInPlace); else MLZ_LAUNCH_ENC(false, false, kEncLdsInPlace); }
             else {  // experiment: software-pipelined kernel (mlz_encode_pipe.hip.inc); same speed, see DESIGN.md section 6
                 if (!c->d_dummy.p) {

@@ -176,13 +176,14 @@ int encode_device_locked(mlz_ctx* c, hipStream_t st, int level, const uint8_t* d
         uint64_t maxlen = 0;
         for (int i = 0; i < n; i++) maxlen = std::max<uint64_t>(maxlen, std::min<uint64_t>(desc[i].src_len, kMaxBlockSize));
         const uint32_t epochs = uint32_t((maxlen + (1u << kEpochLog) - 1) >> kEpochLog);
-        // LevelBalanced currently maps onto the same kernel with far matching forced on
-        // (DESIGN.md "Levels").
+        // LevelBalanced: the same kernel with far matching forced on, both epochs probed and a
+        // cost-aware lazy parse (DESIGN.md "Levels").
         const bool far = (c->encode_far || level == MLZ_LEVEL_BALANCED) && maxlen > kTile;
         static bool enc_attrs = false;
         if (!enc_attrs) {
-            HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(encode_tiles_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, kEncLdsStaged));
-            HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(encode_tiles_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, kEncLdsStaged));
+            HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(encode_tiles_kernel<true, true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, kEncLdsStaged));
+            HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(encode_tiles_kernel<true, true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, kEncLdsStaged));
+            HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(encode_tiles_kernel<false, true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, kEncLdsStaged));
             enc_attrs = true;
         }
         if (far) {
@@ -202,9 +203,10 @@ int encode_device_locked(mlz_ctx* c, hipStream_t st, int level, const uint8_t* d
             Timer t(c, T_ENC_TILES, st);
             unsigned long long* prof = c->prof_on ? c->d_prof.as<unsigned long long>() : nullptr;
             const uint32_t* ftab = far ? c->d_far.as<uint32_t>() : nullptr;
-#define MLZ_LAUNCH_ENC(F, S, LDS)                                                                                                         \
-    hipLaunchKernelGGL((encode_tiles_kernel<F, S>), dim3(tiles), dim3(64), LDS, st, d_src, blocks, tile_block, c->d_scratch.as<uint8_t>(), \
+#define MLZ_LAUNCH_ENC1(F, S, LV, LDS)                                                                                                          \
+    hipLaunchKernelGGL((encode_tiles_kernel<F, S, LV>), dim3(tiles), dim3(64), LDS, st, d_src, blocks, tile_block, c->d_scratch.as<uint8_t>(), \
                        c->d_tile_size.as<uint32_t>(), ftab, epochs, prof)
+#define MLZ_LAUNCH_ENC(F, S, LDS) do { if (F && level == MLZ_LEVEL_BALANCED) MLZ_LAUNCH_ENC1(F, S, 2, LDS); else MLZ_LAUNCH_ENC1(F, S, 1, LDS); } while (0)
             if (c->encode_staged == 1) { if (far) MLZ_LAUNCH_ENC(true, true, kEncLdsStaged); else MLZ_LAUNCH_ENC(false, true, kEncLdsStaged); }
             else if (c->encode_staged == 4) {  // experiment: producer/consumer pair of waves per tile (mlz_encode_pc.hip.inc)
                 if (!c->d_dummy.p) {
@@ -230,6 +232,7 @@ int encode_device_locked(mlz_ctx* c, hipStream_t st, int level, const uint8_t* d
                                         c->d_scratch.as<uint8_t>(), c->d_tile_size.as<uint32_t>(), ftab, epochs, dummy, prof);
             }
 #undef MLZ_LAUNCH_ENC
+#undef MLZ_LAUNCH_ENC1
         }
     }
     {

@@ -12,9 +12,11 @@ from tests.util import load_zip
 
 pytestmark = pytest.mark.gpu
 
-# Stated ratio tolerance (DESIGN.md "Ratio"): C_gpu <= RATIO_TOL * C_oracle_L1 on text-like and
-# JSON-like 8 MiB blocks.
+# Stated ratio tolerances (DESIGN.md "Ratio"), on text-like and JSON-like 8 MiB blocks:
+#   LevelFastest : C_gpu(1) <= RATIO_TOL    * C_oracle(L1)   (measured 1.03 / 1.05)
+#   LevelBalanced: C_gpu(2) <= RATIO_TOL_L2 * C_oracle(L2)   (measured 1.20 / 1.13), and C_gpu(2) <= C_gpu(1)
 RATIO_TOL = 1.15
+RATIO_TOL_L2 = 1.25
 
 
 def roundtrip(d, ctx, level=1):
@@ -93,6 +95,10 @@ def test_ratio_within_tolerance_of_reference_l1(ctx, kind):
     enc = roundtrip(d, ctx)
     ref = O.encode(d, 1)
     assert len(enc) <= RATIO_TOL * len(ref), (len(enc), len(ref))
+    enc2 = roundtrip(d, ctx, level=2)
+    ref2 = O.encode(d, 2)
+    assert len(enc2) <= len(enc), (len(enc2), len(enc))
+    assert len(enc2) <= RATIO_TOL_L2 * len(ref2), (len(enc2), len(ref2))
 
 
 def test_encode_block_contract(ctx):

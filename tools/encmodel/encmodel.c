@@ -30,6 +30,9 @@ typedef struct {
     int lpat;         /* level pattern id */
     int pw_tiles;     /* >0: far table = per-tile table over the last pw_tiles lower-level tiles (most recent wins) */
     int pw_bits;
+    int ways;         /* near table ways (1 or 2: most recent + previous) */
+    int lazy;         /* selection: prefer a match at p+1 that is longer by >= lazy (0 = off) */
+    int far_all;      /* probe both epochs for every position */
 } params;
 
 static inline uint64_t ld64(const uint8_t* p) { uint64_t v; memcpy(&v, p, 8); return v; }
@@ -93,12 +96,14 @@ size_t model_block(const uint8_t* src, size_t n, const params* P, stats* st) {
     }
     uint8_t* depth = (uint8_t*)calloc(n + 8, 1);
     uint16_t* table = (uint16_t*)malloc(sizeof(uint16_t) << P->hash_bits);
+    uint16_t* table2 = (uint16_t*)malloc(sizeof(uint16_t) << P->hash_bits);
     uint32_t* pwtab = P->pw_tiles ? (uint32_t*)malloc(sizeof(uint32_t) << P->pw_bits) : NULL;
     uint8_t* hole = (uint8_t*)malloc(T + 8);
     for (size_t t = 0; t < ntiles; t++) {
         size_t base = t * T, tl = n - base < T ? n - base : T;
         const uint8_t* s = src + base;
         memset(table, 0, sizeof(uint16_t) << P->hash_bits);
+        memset(table2, 0, sizeof(uint16_t) << P->hash_bits);
         memset(hole, 0, T + 8);
         if (pwtab) {
             memset(pwtab, 0xff, sizeof(uint32_t) << P->pw_bits);
@@ -117,7 +122,7 @@ size_t model_block(const uint8_t* src, size_t n, const params* P, stats* st) {
         while (cur + 8 <= tl) {
             size_t s0 = cur;
             /* phase 1: all lanes look up */
-            uint16_t cand[64]; uint32_t hh[64]; int valid[64];
+            uint16_t cand[64]; uint16_t cand2[64]; uint32_t hh[64]; int valid[64];
             size_t len_[64], off_[64]; int isrep[64], isfar[64];
             for (int i = 0; i < W; i++) {
                 size_t p = s0 + i;
@@ -126,9 +131,9 @@ size_t model_block(const uint8_t* src, size_t n, const params* P, stats* st) {
                 if (!valid[i]) continue;
                 uint64_t v = ld64(s + p);
                 hh[i] = hashN(v, P->hash_bytes, P->hash_bits);
-                cand[i] = table[hh[i]];
+                cand[i] = table[hh[i]]; cand2[i] = table2[hh[i]];
             }
-            for (int i = 0; i < W; i++) if (valid[i]) table[hh[i]] = (uint16_t)(s0 + i); /* highest lane wins */
+            for (int i = 0; i < W; i++) if (valid[i]) { if (P->ways > 1) { uint16_t old = table[hh[i]]; if (old < s0) table2[hh[i]] = old; } table[hh[i]] = (uint16_t)(s0 + i); } /* highest lane wins */
             for (int i = 0; i < W; i++) {
                 if (!valid[i]) continue;
                 size_t p = s0 + i, maxl = tl - p;
@@ -140,6 +145,10 @@ size_t model_block(const uint8_t* src, size_t n, const params* P, stats* st) {
                 if (cand[i] < p) {
                     size_t l = mlen(s + p, s + cand[i], maxl);
                     if (l >= 4 && (!brep || l > best + 1)) { if (!brep || l > best + 1) { best = l; boff = p - cand[i]; brep = 0; } }
+                }
+                if (P->ways > 1 && cand2[i] < p && cand2[i] != cand[i]) {
+                    size_t l = mlen(s + p, s + cand2[i], maxl);
+                    if (l >= 4 && l > best + 1) { best = l; boff = p - cand2[i]; brep = 0; }
                 }
                 int mylv = tile_level(t, P);
                 if (pwtab && mylv > 0) {
@@ -158,6 +167,7 @@ size_t model_block(const uint8_t* src, size_t n, const params* P, stats* st) {
                     size_t ep = (base + p) >> P->epoch_log;
                     for (int k = 0; k < 2; k++) {
                         if ((size_t)k > ep) break;
+                        if (k == 1 && !P->far_all && ((base + p) & (E - 1)) >= E / 2) break;
                         size_t LS = P->nlevels ? (size_t)(mylv - 1) : 0;
                         uint32_t q = far_tab[((LS * nepoch + (ep - k)) << P->far_bits) + h];
                         if (q == 0xffffffffu || q >= base) continue; /* strictly before this tile */
@@ -174,6 +184,7 @@ size_t model_block(const uint8_t* src, size_t n, const params* P, stats* st) {
             for (int i = 0; i < W; i++) {
                 size_t p = s0 + i;
                 if (p < pos || !valid[i] || len_[i] < 4) continue;
+                if (P->lazy && i + 1 < W && valid[i + 1] && len_[i + 1] >= len_[i] + (size_t)P->lazy) continue;
                 size_t L = len_[i], off = off_[i]; int r = isrep[i], f = isfar[i];
                 size_t pp = p;
                 if (P->back_ext) {
@@ -206,7 +217,7 @@ size_t model_block(const uint8_t* src, size_t n, const params* P, stats* st) {
         if (out > tl + 4) out = tl + 4;
         total += out;
     }
-    free(table); free(hole); free(far_tab); free(depth); free(pwtab);
+    free(table); free(table2); free(hole); free(far_tab); free(depth); free(pwtab);
     if (st) st->out += total;
     return total;
 }

@@ -26,7 +26,9 @@ extern "C" {
 
 #define MLZ_MAX_BLOCK_SIZE (8u << 20) /* minlz.go:84 MaxBlockSize */
 
-/* compression levels, encode.go:25-43 */
+/* compression levels, encode.go:25-43.  LevelSmallest (3) is not offered on the device: encode calls
+ * return -MLZ_ERR_INVALID_LEVEL for it, which a WriterCustomEncoder treats as "decline". */
+#define MLZ_LEVEL_SUPERFAST (-1)
 #define MLZ_LEVEL_UNCOMPRESSED 0
 #define MLZ_LEVEL_FASTEST 1
 #define MLZ_LEVEL_BALANCED 2

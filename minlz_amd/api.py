@@ -7,7 +7,7 @@ import numpy as np
 from . import _lib
 from ._lib import BlockDesc
 
-LevelUncompressed, LevelFastest, LevelBalanced = 0, 1, 2  # encode.go:25-43
+LevelSuperFast, LevelUncompressed, LevelFastest, LevelBalanced = -1, 0, 1, 2  # encode.go:25-43 (LevelSmallest = 3 is CPU-only)
 MaxBlockSize = 8 << 20  # minlz.go:84
 
 OPT_DECODE_ALGO, OPT_ENCODE_FAR, OPT_TIMING = 1, 2, 100
@@ -179,7 +179,7 @@ def AppendEncoded(dst, src, level=LevelFastest, ctx=None):
 def TryEncode(src, level=LevelFastest, ctx=None):
     """encode.go:168-206: None when incompressible."""
     a = _np(src)
-    if MaxEncodedLen(a.size) < 0 or a.size < 16 or level not in (LevelFastest, LevelBalanced):
+    if MaxEncodedLen(a.size) < 0 or a.size < 16 or level not in (LevelSuperFast, LevelFastest, LevelBalanced):
         return None
     e = Encode(a, level, ctx)
     if len(e) >= 2 and e[0] == 0 and e[1] == 0:

@@ -46,6 +46,9 @@ struct DevBuf {
 constexpr size_t kProfTiles = 4096;                      // debug timeline: tiles recorded by the exec pass
 constexpr size_t kProfBytes = 256 + kProfTiles * 32;
 
+// Levels served on the device (encode.go:25-43); LevelSmallest (3) stays on the host side of the boundary.
+inline bool valid_level(int level) { return level >= MLZ_LEVEL_SUPERFAST && level <= MLZ_LEVEL_BALANCED; }
+
 enum { T_FAR = 0, T_ENC_TILES, T_ENC_LAYOUT, T_ENC_GATHER, T_DEC_PARSE, T_DEC_CHAIN, T_DEC_INDEX, T_DEC_EXEC, T_DEC_SERIAL, T_CRC, T_COUNT };
 const char* kTimerNames[T_COUNT] = {"enc_far_build", "enc_tiles", "enc_layout", "enc_gather", "dec_parse", "dec_chain", "dec_index", "dec_exec", "dec_serial", "crc"};
 
@@ -160,7 +163,7 @@ int upload_blocks(mlz_ctx* c, hipStream_t st, const mlz_block_desc* desc, int n,
 
 int encode_device_locked(mlz_ctx* c, hipStream_t st, int level, const uint8_t* d_src, uint8_t* d_dst, const mlz_block_desc* desc, int n,
                          int64_t* d_out_len, bool with_header) {
-    if (level != MLZ_LEVEL_UNCOMPRESSED && level != MLZ_LEVEL_FASTEST && level != MLZ_LEVEL_BALANCED) return -MLZ_ERR_INVALID_LEVEL;
+    if (!valid_level(level)) return -MLZ_ERR_INVALID_LEVEL;
     if (n <= 0) return 0;
     HIPCHK(c, hipSetDevice(c->device));
     uint32_t tiles = 0;
@@ -178,7 +181,8 @@ int encode_device_locked(mlz_ctx* c, hipStream_t st, int level, const uint8_t* d
         const uint32_t epochs = uint32_t((maxlen + (1u << kEpochLog) - 1) >> kEpochLog);
         // LevelBalanced: the same kernel with far matching forced on, both epochs probed and a
         // cost-aware lazy parse (DESIGN.md "Levels").
-        const bool far = (c->encode_far || level == MLZ_LEVEL_BALANCED) && maxlen > kTile;
+        // LevelSuperFast: tile-local matches only (no far tables are built or probed).
+        const bool far = ((c->encode_far && level != MLZ_LEVEL_SUPERFAST) || level == MLZ_LEVEL_BALANCED) && maxlen > kTile;
         static bool enc_attrs = false;
         if (!enc_attrs) {
             HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(encode_tiles_kernel<true, true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, kEncLdsStaged));
@@ -489,7 +493,7 @@ int64_t mlz_encode(mlz_ctx* c, int level, const uint8_t* src, size_t n, uint8_t*
     if (!c || (!src && n) || !dst) return -MLZ_ERR_ARG;
     if (n > kMaxBlockSize) return -MLZ_ERR_TOO_LARGE;
     if (int64_t(dst_cap) < mlz_max_encoded_len(n)) return -MLZ_ERR_DST_TOO_SMALL;
-    if (level != 0 && level != 1 && level != 2) return n < kMinNonLiteralBlock ? -MLZ_ERR_INVALID_LEVEL : -MLZ_ERR_INVALID_LEVEL;
+    if (!valid_level(level)) return -MLZ_ERR_INVALID_LEVEL;
     int64_t out = 0;
     int r = host_batch(c, true, level, 1, &src, &n, &dst, &dst_cap, &out, true, nullptr);
     return r ? r : out;
@@ -534,7 +538,7 @@ int mlz_encode_batch(mlz_ctx* c, int level, int n, const uint8_t* const* src, co
                      int64_t* out_len) {
     if (!c || n < 0) return -MLZ_ERR_ARG;
     if (n == 0) return 0;
-    if (level != 0 && level != 1 && level != 2) return -MLZ_ERR_INVALID_LEVEL;
+    if (!valid_level(level)) return -MLZ_ERR_INVALID_LEVEL;
     return host_batch(c, true, level, n, src, src_len, dst, dst_cap, out_len, true, nullptr);
 }
 

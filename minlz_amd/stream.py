@@ -5,7 +5,8 @@ type 0x02 with body `uvarint(N) tokens` when the block compressed, 0x01 with the
 otherwise (writer.go:876-910); the stream starts with `ff 06 00 00 "MinLz" (log2(blockSize)-10)`
 (writer.go:1553-1556) and ends with the EOF chunk `20 len uvarint(total)` (writer.go:1063-1074).
 Blocks are handed to a *backend* in batches — one launch per batch on the GPU instead of one
-goroutine per block (writer.go:501-560, reader.go:830-859).  No index / padding / search tables.
+goroutine per block (writer.go:501-560, reader.go:830-859).  The seek index (index.py) can be
+appended after the EOF chunk (WriterAddIndex) and drives ReadSeeker; no padding / search tables.
 
 Backends: HipBackend (the product: everything on the device through the C ABI).  Tests inject an
 oracle-based backend to exercise this host logic without a GPU.
@@ -13,6 +14,7 @@ oracle-based backend to exercise this host logic without a GPU.
 import io
 
 from . import api
+from .index import Index
 
 MAGIC = b"\xff\x06\x00\x00MinLz"
 CHUNK_UNCOMPRESSED, CHUNK_MINLZ, CHUNK_MINLZ_COMPCRC, CHUNK_EOF, CHUNK_STREAM_ID = 0x01, 0x02, 0x03, 0x20, 0xFF
@@ -70,10 +72,10 @@ class HipBackend:
 class Writer:
     """NewWriter(w, WriterLevel(level), WriterBlockSize(bs), WriterConcurrency(n)) (writer.go:35-86)."""
 
-    def __init__(self, w, level=api.LevelBalanced, block_size=DEFAULT_BLOCK, concurrency=16, backend=None):
+    def __init__(self, w, level=api.LevelBalanced, block_size=DEFAULT_BLOCK, concurrency=16, backend=None, add_index=False):
         if not (MIN_BLOCK <= block_size <= MAX_BLOCK):
             raise ValueError("minlz: block size must be 4KiB..8MiB")  # writer.go:1238-1246
-        if level not in (api.LevelUncompressed, api.LevelFastest, api.LevelBalanced):
+        if level not in (api.LevelSuperFast, api.LevelUncompressed, api.LevelFastest, api.LevelBalanced):
             raise api.ErrInvalidLevel()
         self.w, self.level, self.block_size, self.batch = w, level, block_size, max(1, concurrency)
         self.backend = backend or HipBackend()
@@ -82,6 +84,10 @@ class Writer:
         self.written = 0          # Written(): compressed bytes so far (writer.go:1041)
         self.uncomp_written = 0
         self.closed = False
+        self.add_index = add_index  # WriterAddIndex (writer.go:1194-1204)
+        self.index = Index()        # always generated (WriterCreateIndex default, writer.go:41)
+        self.index.reset(block_size)
+        self.index_bytes = None
 
     def _emit(self, b):
         self.w.write(b)
@@ -109,6 +115,7 @@ class Writer:
                 else:
                     ctype, payload = CHUNK_UNCOMPRESSED, blk
                 clen = 4 + len(payload)
+                self.index.add(self.written, self.uncomp_written)  # writer.go:945
                 self._emit(bytes([ctype, clen & 0xFF, (clen >> 8) & 0xFF, (clen >> 16) & 0xFF]) + crc.to_bytes(4, "little") + payload)
                 self.uncomp_written += len(blk)
 
@@ -133,7 +140,15 @@ class Writer:
         self._flush_blocks(True)
         v = put_uvarint(self.uncomp_written)
         self._emit(bytes([CHUNK_EOF, len(v), 0, 0]) + v)  # writer.go:1063-1074
+        self.index_bytes = self.index.append_to(self.uncomp_written, self.written)  # writer.go:1080-1088
+        if self.add_index:
+            self._emit(self.index_bytes)
         self.closed = True
+
+    def CloseIndex(self):
+        """Close and return the index chunk (writer.go:1045-1049); it is part of the stream only with add_index."""
+        self.Close()
+        return self.index_bytes
 
     def Written(self):
         return self.written
@@ -148,6 +163,7 @@ class Reader:
         self.ignore_crc = ignore_crc
         self.batch = max(1, batch)
         self.backend = backend or HipBackend()
+        self.partial = False  # set by ReadSeeker: the input is a fragment cut at chunk boundaries
 
     def _read_full(self, n, allow_eof=False):
         b = self.r.read(n)
@@ -185,7 +201,7 @@ class Reader:
         stream_out = 0
         pending = []
         while True:
-            hdr = self._read_full(4, allow_eof=not want_eof)
+            hdr = self._read_full(4, allow_eof=not want_eof or self.partial)
             if hdr is None:
                 break
             ctype = hdr[0]
@@ -227,7 +243,7 @@ class Reader:
                 if clen:
                     buf = self._read_full(clen)
                     want, vn = uvarint(buf)
-                    if vn != clen or want != stream_out:
+                    if vn != clen or (want != stream_out and not self.partial):
                         raise api.ErrCorrupt("EOF length mismatch")  # reader.go:476-491
                 want_eof = read_header = False
             elif ctype == CHUNK_STREAM_ID:
@@ -264,3 +280,70 @@ class Reader:
         out = io.BytesIO()
         self.WriteTo(out)
         return out.getvalue()
+
+
+class ReadSeeker:
+    """Reader.ReadSeeker(index) (reader.go:1304-1487): random access into a stream held in memory.
+
+    `index` = index chunk bytes (Writer.CloseIndex()), or None to load it from the end of the stream
+    (Index.LoadStream).  Seek positions by uncompressed offset: the index gives the last indexed
+    block at or before it, decoding starts there and the bytes in front are discarded."""
+
+    def __init__(self, stream, index=None, backend=None, **reader_kw):
+        self.stream = bytes(stream)
+        self.backend = backend
+        self.reader_kw = reader_kw
+        self.idx = Index()
+        if index is None:
+            self.idx.load_stream(self.stream)
+        else:
+            self.idx.load(index)
+        self.pos = 0
+        self._cache = (None, b"")  # (uncompressed offset of the cached span, its bytes)
+
+    def Index(self):
+        return self.idx
+
+    def Seek(self, offset, whence=0):
+        if whence == 0:
+            absolute = offset
+        elif whence == 1:
+            absolute = self.pos + offset
+        elif whence == 2:
+            absolute = self.idx.total_uncompressed + offset
+        else:
+            raise api.ErrUnsupported()
+        if absolute < 0:
+            raise ValueError("seek before start of file")
+        self.idx.find(absolute)  # validates the range (io.ErrUnexpectedEOF beyond the end)
+        self.pos = absolute
+        return absolute
+
+    def _span(self, c_off, u_off, want_end):
+        """Decode from the indexed chunk at c_off until the output covers want_end."""
+        cu, cached = self._cache
+        if cu == u_off and u_off + len(cached) >= want_end:
+            return cached
+        nxt = [c for c, u in self.idx.offsets if u >= want_end and c > c_off]
+        c_end = nxt[0] if nxt else len(self.stream)
+        # a stream fragment starting at a chunk boundary: prepend the stream header so the Reader accepts it
+        head = self.stream[:10] if self.stream[:4] == MAGIC[:4] else b""
+        frag = head + self.stream[c_off if c_off else len(head):c_end]
+        out = io.BytesIO()
+        r = Reader(frag, backend=self.backend, **self.reader_kw) if self.backend else Reader(frag, **self.reader_kw)
+        r.partial = c_end != len(self.stream) or c_off != 0
+        r.WriteTo(out)
+        data = out.getvalue()
+        self._cache = (u_off, data)
+        return data
+
+    def ReadAt(self, n, offset):
+        c_off, u_off = self.idx.find(offset)
+        end = min(offset + n, self.idx.total_uncompressed)
+        data = self._span(c_off, u_off, end)
+        return data[offset - u_off:end - u_off]
+
+    def Read(self, n):
+        b = self.ReadAt(n, self.pos)
+        self.pos += len(b)
+        return b

@@ -895,9 +895,18 @@ static unsigned bits_len(size_t v) { unsigned n = 0; while (v) { n++; v >>= 1; }
 
 /* Writer sync path: makeHeader (writer.go:1553-1556), per block (writer.go:876-959), EOF chunk
  * (writer.go:1063-1074).  No index, no padding. */
+long mlzo_stream_encode_ex(uint8_t* dst, size_t dcap, const uint8_t* src, size_t n, int level, size_t block_size, int add_index);
 long mlzo_stream_encode(uint8_t* dst, size_t dcap, const uint8_t* src, size_t n, int level, size_t block_size) {
+    return mlzo_stream_encode_ex(dst, dcap, src, n, level, block_size, 0);
+}
+/* add_index: WriterAddIndex(true) — the index chunk follows the EOF chunk (writer.go:1080-1122). */
+long mlzo_stream_encode_ex(uint8_t* dst, size_t dcap, const uint8_t* src, size_t n, int level, size_t block_size, int add_index) {
     if (block_size > MLZO_MAX_BLOCK_SIZE || block_size < (4 << 10)) return -MLZO_ERR_TOO_LARGE; /* writer.go:1238-1246 */
-    if (dcap < mlzo_stream_bound(n, block_size)) return -MLZO_ERR_DST_TOO_SMALL;
+    const size_t nblocks = (n + block_size - 1) / block_size;
+    if (dcap < mlzo_stream_bound(n, block_size) + (add_index ? mlzo_index_bound(nblocks) : 0)) return -MLZO_ERR_DST_TOO_SMALL;
+    int64_t* ic = add_index ? (int64_t*)malloc(sizeof(int64_t) * (nblocks + 1)) : NULL;
+    int64_t* iu = add_index ? (int64_t*)malloc(sizeof(int64_t) * (nblocks + 1)) : NULL;
+    size_t nb = 0;
     size_t o = 0;
     if (n > 0) { /* header is written lazily with the first block */
         memcpy(dst, MAGIC_CHUNK, 9); dst[9] = (uint8_t)(bits_len(block_size - 1) - 10); o = 10;
@@ -915,8 +924,9 @@ long mlzo_stream_encode(uint8_t* dst, size_t dcap, const uint8_t* src, size_t n,
         case 1: n2 = mlzo_encode_block_l1(ob + 8 + vn, u, bl); break;
         case 2: n2 = mlzo_encode_block_l2(ob + 8 + vn, u, bl); break;
         case 3: n2 = mlzo_encode_block_l3(ob + 8 + vn, u, bl); break;
-        default: return -MLZO_ERR_INVALID_LEVEL;
+        default: free(ic); free(iu); return -MLZO_ERR_INVALID_LEVEL;
         }
+        if (add_index) { ic[nb] = (int64_t)o; iu[nb] = (int64_t)pos; nb++; } /* index.add(w.written, w.uncompWritten), writer.go:945 */
         size_t chunk_len; uint8_t type;
         if (n2 > 0) { type = 0x02; chunk_len = 4 + vn + n2; }
         else { type = 0x01; chunk_len = 4 + bl; memcpy(ob + 8, u, bl); }
@@ -930,7 +940,169 @@ long mlzo_stream_encode(uint8_t* dst, size_t dcap, const uint8_t* src, size_t n,
     int vn = put_uvarint(e + 4, n);
     e[0] = 0x20; e[1] = (uint8_t)vn; e[2] = 0; e[3] = 0;
     o += 4 + vn;
+    if (add_index) {
+        long k = mlzo_index_build(dst + o, dcap - o, ic, iu, nb, block_size, (int64_t)n, (int64_t)o);
+        free(ic); free(iu);
+        if (k < 0) return k;
+        o += (size_t)k;
+    }
     return (long)o;
+}
+
+/* ---- seek index (index.go:26-414, SPEC.md:477-575) ---- */
+#define MAX_INDEX_ENTRIES (1 << 16)
+#define MIN_INDEX_DIST (1 << 20)
+static const uint8_t INDEX_HEADER[6] = {'s', '2', 'i', 'd', 'x', 0};
+static const uint8_t INDEX_TRAILER[6] = {0, 'x', 'd', 'i', '2', 's'};
+
+static size_t put_varint(uint8_t* d, int64_t v) { /* binary.PutVarint: zigzag + uvarint */
+    uint64_t u = ((uint64_t)v << 1) ^ (uint64_t)(v >> 63);
+    return put_uvarint(d, u);
+}
+static int get_varint(const uint8_t* b, size_t n, int64_t* v) { /* binary.Varint; <= 0 on error */
+    uint64_t x = 0; unsigned sh = 0;
+    for (size_t i = 0; i < n && i < 10; i++) {
+        uint8_t c = b[i];
+        if (c < 0x80) {
+            if (i == 9 && c > 1) return -1;
+            x |= (uint64_t)c << sh;
+            *v = (int64_t)(x >> 1) ^ -(int64_t)(x & 1);
+            return (int)i + 1;
+        }
+        x |= (uint64_t)(c & 0x7f) << sh; sh += 7;
+    }
+    return 0;
+}
+
+typedef struct { int64_t est; long n; int64_t* c; int64_t* u; } mlzo_index;
+
+static void index_reduce_light(mlzo_index* ix) { /* index.go:176-189 */
+    ix->est *= 2;
+    long j = 0;
+    for (long i = 0; i < ix->n; i++) {
+        int64_t bc = ix->c[i], bu = ix->u[i];
+        ix->c[j] = bc; ix->u[j] = bu; j++;
+        while (i < ix->n && ix->u[i] - bu < ix->est) i++;
+    }
+    ix->n = j;
+}
+static void index_add(mlzo_index* ix, int64_t c_off, int64_t u_off) { /* index.go:80-104 */
+    if (ix->n > 0 && u_off - ix->u[ix->n - 1] < ix->est) return;
+    ix->c[ix->n] = c_off; ix->u[ix->n] = u_off; ix->n++;
+    if (ix->n > MAX_INDEX_ENTRIES) index_reduce_light(ix);
+}
+static void index_reduce(mlzo_index* ix) { /* index.go:150-173 */
+    if (ix->n < MAX_INDEX_ENTRIES) return;
+    long remove_n = (ix->n + 1) / MAX_INDEX_ENTRIES;
+    while (ix->est * (remove_n + 1) < MIN_INDEX_DIST && ix->n / (remove_n + 1) > 1000) remove_n++;
+    long j = 0;
+    for (long i = 0; i < ix->n; i++) { ix->c[j] = ix->c[i]; ix->u[j] = ix->u[i]; j++; i += remove_n; }
+    ix->n = j;
+    ix->est += ix->est * remove_n;
+}
+static size_t index_append(uint8_t* b, mlzo_index* ix, int64_t total_u, int64_t total_c) { /* appendTo, index.go:191-269 */
+    index_reduce(ix);
+    size_t o = 0;
+    b[o++] = 0x40; b[o++] = 0; b[o++] = 0; b[o++] = 0;
+    memcpy(b + o, INDEX_HEADER, 6); o += 6;
+    o += put_varint(b + o, total_u);
+    o += put_varint(b + o, total_c);
+    o += put_varint(b + o, ix->est);
+    o += put_varint(b + o, ix->n);
+    uint8_t has_u = 0;
+    for (long i = 0; i < ix->n; i++) {
+        if (i == 0) { if (ix->u[0] != 0) { has_u = 1; break; } continue; }
+        if (ix->u[i] != ix->u[i - 1] + ix->est) { has_u = 1; break; }
+    }
+    b[o++] = has_u;
+    if (has_u)
+        for (long i = 0; i < ix->n; i++) {
+            int64_t u = ix->u[i];
+            if (i > 0) u -= ix->u[i - 1] + ix->est;
+            o += put_varint(b + o, u);
+        }
+    int64_t predict = ix->est / 2;
+    for (long i = 0; i < ix->n; i++) {
+        int64_t c = ix->c[i];
+        if (i > 0) { c -= ix->c[i - 1] + predict; predict += c / 2; }
+        o += put_varint(b + o, c);
+    }
+    st32(b, o, (uint32_t)(o + 4 + 6)); o += 4;
+    memcpy(b + o, INDEX_TRAILER, 6); o += 6;
+    size_t chunk_len = o - 4;
+    b[1] = (uint8_t)chunk_len; b[2] = (uint8_t)(chunk_len >> 8); b[3] = (uint8_t)(chunk_len >> 16);
+    return o;
+}
+
+size_t mlzo_index_bound(size_t n_blocks) { return 64 + 20 * (n_blocks < MAX_INDEX_ENTRIES + 1 ? n_blocks : MAX_INDEX_ENTRIES + 1); }
+
+/* Index.reset(block_size) + add(c_off[i], u_off[i]) for every block + appendTo.  Returns index bytes. */
+long mlzo_index_build(uint8_t* dst, size_t cap, const int64_t* c_off, const int64_t* u_off, size_t n_blocks, size_t block_size,
+                      int64_t total_u, int64_t total_c) {
+    if (cap < mlzo_index_bound(n_blocks)) return -MLZO_ERR_DST_TOO_SMALL;
+    mlzo_index ix;
+    int64_t mb = (int64_t)block_size;
+    while (mb < MIN_INDEX_DIST) mb *= 2; /* reset, index.go:56-68 */
+    ix.est = mb; ix.n = 0;
+    ix.c = (int64_t*)malloc(sizeof(int64_t) * (MAX_INDEX_ENTRIES + 2));
+    ix.u = (int64_t*)malloc(sizeof(int64_t) * (MAX_INDEX_ENTRIES + 2));
+    for (size_t i = 0; i < n_blocks; i++) index_add(&ix, c_off[i], u_off[i]);
+    size_t n = index_append(dst, &ix, total_u, total_c);
+    free(ix.c); free(ix.u);
+    return (long)n;
+}
+
+/* Index.Load, index.go:273-396.  Returns MLZO_* (MLZO_ERR_CORRUPT also for short input); *consumed = bytes of b used. */
+int mlzo_index_load(const uint8_t* b, size_t n, int64_t* total_u, int64_t* total_c, int64_t* est, int64_t* c_off, int64_t* u_off,
+                    size_t cap, size_t* n_entries, size_t* consumed) {
+    size_t p = 0;
+    if (n <= 4 + 6 + 6) return MLZO_ERR_CORRUPT;
+    if (b[0] != 0x40 && b[0] != 0x99) return MLZO_ERR_CORRUPT;
+    size_t chunk_len = (size_t)b[1] | (size_t)b[2] << 8 | (size_t)b[3] << 16;
+    p = 4;
+    if (n - p < chunk_len) return MLZO_ERR_CORRUPT;
+    if (memcmp(b + p, INDEX_HEADER, 6) != 0) return MLZO_ERR_UNSUPPORTED;
+    p += 6;
+    int64_t v; int k;
+    if ((k = get_varint(b + p, n - p, &v)) <= 0 || v < 0) return MLZO_ERR_CORRUPT;
+    *total_u = v; p += k;
+    if ((k = get_varint(b + p, n - p, &v)) <= 0) return MLZO_ERR_CORRUPT;
+    *total_c = v; p += k;
+    if ((k = get_varint(b + p, n - p, &v)) <= 0 || v < 0) return MLZO_ERR_CORRUPT;
+    *est = v; p += k;
+    if ((k = get_varint(b + p, n - p, &v)) <= 0 || v < 0 || v > MAX_INDEX_ENTRIES) return MLZO_ERR_CORRUPT;
+    size_t entries = (size_t)v; p += k;
+    if (entries > cap) return MLZO_ERR_DST_TOO_SMALL;
+    if (n - p < 1) return MLZO_ERR_CORRUPT;
+    uint8_t has_u = b[p++];
+    if ((has_u & 1) != has_u) return MLZO_ERR_CORRUPT;
+    for (size_t i = 0; i < entries; i++) {
+        int64_t u = 0;
+        if (has_u) { if ((k = get_varint(b + p, n - p, &u)) <= 0) return MLZO_ERR_CORRUPT; p += k; }
+        if (i > 0) { int64_t prev = u_off[i - 1]; u += prev + *est; if (u <= prev) return MLZO_ERR_CORRUPT; }
+        if (u < 0) return MLZO_ERR_CORRUPT;
+        u_off[i] = u;
+    }
+    int64_t predict = *est / 2;
+    for (size_t i = 0; i < entries; i++) {
+        int64_t c;
+        if ((k = get_varint(b + p, n - p, &c)) <= 0) return MLZO_ERR_CORRUPT;
+        p += k;
+        if (i > 0) {
+            int64_t pn = predict + c / 2, prev = c_off[i - 1];
+            c += prev + predict;
+            if (c <= prev) return MLZO_ERR_CORRUPT;
+            predict = pn;
+        }
+        if (c < 0) return MLZO_ERR_CORRUPT;
+        c_off[i] = c;
+    }
+    if (n - p < 4 + 6) return MLZO_ERR_CORRUPT;
+    p += 4;
+    if (memcmp(b + p, INDEX_TRAILER, 6) != 0) return MLZO_ERR_CORRUPT;
+    p += 6;
+    *n_entries = entries; *consumed = p;
+    return MLZO_OK;
 }
 
 /* Reader.Read, reader.go:248-543, for MinLZ streams (no Snappy/S2 fallback). */

@@ -75,6 +75,14 @@ uint32_t mlzo_crc(const uint8_t* b, size_t n); /* minlz.go:137-140 masked CRC32C
 size_t mlzo_stream_bound(size_t n, size_t block_size);
 /* Writer(level, blockSize).EncodeBuffer(src); Close() — no index, no padding. */
 long mlzo_stream_encode(uint8_t* dst, size_t dcap, const uint8_t* src, size_t n, int level, size_t block_size);
+/* ... with WriterAddIndex(add_index): the seek index chunk (0x40) follows the EOF chunk. */
+long mlzo_stream_encode_ex(uint8_t* dst, size_t dcap, const uint8_t* src, size_t n, int level, size_t block_size, int add_index);
+/* seek index (index.go:26-414; SPEC.md:477-575).  build = reset(block_size) + add() per block + appendTo. */
+size_t mlzo_index_bound(size_t n_blocks);
+long mlzo_index_build(uint8_t* dst, size_t cap, const int64_t* c_off, const int64_t* u_off, size_t n_blocks, size_t block_size,
+                      int64_t total_u, int64_t total_c);
+int mlzo_index_load(const uint8_t* b, size_t n, int64_t* total_u, int64_t* total_c, int64_t* est, int64_t* c_off, int64_t* u_off,
+                    size_t cap, size_t* n_entries, size_t* consumed);
 /* Reader.Read until EOF. Returns MLZO_*; *dlen = bytes produced. */
 int mlzo_stream_decode(const uint8_t* src, size_t slen, uint8_t* dst, size_t dcap, size_t* dlen);
 

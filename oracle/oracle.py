@@ -159,11 +159,15 @@ def crc(b):
     return lib().mlzo_crc(p, n)
 
 
-def stream_encode(src, level=1, block_size=8 << 20):
+def stream_encode(src, level=1, block_size=8 << 20, add_index=False):
     a, p, n = _buf(src)
-    cap_ = lib().mlzo_stream_bound(n, block_size)
+    L = lib()
+    L.mlzo_index_bound.argtypes = [C.c_size_t]; L.mlzo_index_bound.restype = C.c_size_t
+    L.mlzo_stream_encode_ex.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int, C.c_size_t, C.c_int]
+    L.mlzo_stream_encode_ex.restype = C.c_long
+    cap_ = L.mlzo_stream_bound(n, block_size) + (L.mlzo_index_bound((n + block_size - 1) // block_size) if add_index else 0)
     out = np.empty(cap_, dtype=np.uint8)
-    r = lib().mlzo_stream_encode(out.ctypes.data, cap_, p, n, level, block_size)
+    r = L.mlzo_stream_encode_ex(out.ctypes.data, cap_, p, n, level, block_size, 1 if add_index else 0)
     if r < 0:
         raise OracleError(-r)
     return out[:r].tobytes()
@@ -190,3 +194,34 @@ def bench_encode(src, block_size, level, threads, reps=1):
 def bench_decode(src, block_size, level, threads, reps=1):
     a, p, n = _buf(src)
     return lib().mlzo_bench_decode(p, n, block_size, level, threads, reps)
+
+
+def index_build(c_off, u_off, block_size, total_u, total_c):
+    """Index.reset(block_size) + add() per block + appendTo (index.go:56-269) -> index chunk bytes."""
+    L = lib()
+    L.mlzo_index_bound.argtypes = [C.c_size_t]; L.mlzo_index_bound.restype = C.c_size_t
+    L.mlzo_index_build.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int64, C.c_int64]
+    L.mlzo_index_build.restype = C.c_long
+    c = np.ascontiguousarray(c_off, dtype=np.int64); u = np.ascontiguousarray(u_off, dtype=np.int64)
+    cap_ = L.mlzo_index_bound(c.size)
+    out = np.empty(cap_, dtype=np.uint8)
+    r = L.mlzo_index_build(out.ctypes.data, cap_, c.ctypes.data, u.ctypes.data, c.size, block_size, total_u, total_c)
+    if r < 0:
+        raise OracleError(-r)
+    return out[:r].tobytes()
+
+
+def index_load(b):
+    """Index.Load (index.go:273-396) -> (total_u, total_c, est_block, [(c_off, u_off)...], consumed)."""
+    L = lib()
+    L.mlzo_index_load.argtypes = [C.c_void_p, C.c_size_t] + [C.c_void_p] * 5 + [C.c_size_t, C.c_void_p, C.c_void_p]
+    L.mlzo_index_load.restype = C.c_int
+    a, p, n = _buf(b)
+    tu, tc, est = C.c_int64(), C.c_int64(), C.c_int64()
+    co = np.zeros(1 << 16, dtype=np.int64); uo = np.zeros(1 << 16, dtype=np.int64)
+    ne, used = C.c_size_t(), C.c_size_t()
+    r = L.mlzo_index_load(p, n, C.byref(tu), C.byref(tc), C.byref(est), co.ctypes.data, uo.ctypes.data, co.size, C.byref(ne), C.byref(used))
+    if r:
+        raise OracleError(r)
+    k = ne.value
+    return tu.value, tc.value, est.value, list(zip(co[:k].tolist(), uo[:k].tolist())), used.value

@@ -42,6 +42,17 @@ def test_block_container_rules(ctx):
         mz.Encode(np.zeros((8 << 20) + 1, dtype=np.uint8), 1, ctx)
     with pytest.raises(mz.ErrInvalidLevel):
         mz.Encode(bytes(100), 7, ctx)
+    with pytest.raises(mz.ErrInvalidLevel):
+        mz.Encode(bytes(100), 3, ctx)  # LevelSmallest is CPU-side only
+
+
+def test_level_superfast(ctx):
+    # LevelSuperFast (-1, encode.go:26-29): tile-local matching only; valid stream, worse ratio, no far tables
+    d = synth.text_like(4 << 20, 6)
+    e0 = roundtrip(d, ctx, level=mz.LevelSuperFast)
+    e1 = roundtrip(d, ctx, level=mz.LevelFastest)
+    assert len(e1) <= len(e0) < d.size
+    assert mz.Decode(e0, ctx) == d.tobytes()
 
 
 @pytest.mark.parametrize("far", [0, 1])

@@ -54,3 +54,22 @@ def test_reader_detects_corruption(ctx):
     s[len(s) // 2] ^= 0x10
     with pytest.raises((mz.ErrCRC, mz.ErrCorrupt)):
         S.Reader(bytes(s), backend=be).ReadAll()
+
+
+def test_index_and_read_seeker_on_device(ctx):
+    # WriterAddIndex + Reader.ReadSeeker (index.go, reader.go:1304-1487) with every block on the GPU
+    import random
+    d = synth.text_like(20 << 20, 12).tobytes()
+    w = io.BytesIO()
+    wr = S.Writer(w, level=1, block_size=1 << 20, concurrency=8, backend=S.HipBackend(ctx), add_index=True)
+    wr.EncodeBuffer(d)
+    idx = wr.CloseIndex()
+    st = w.getvalue()
+    assert st.endswith(idx) and O.stream_decode(st, len(d)) == d         # the reference-side reader skips chunk 0x40
+    tu, tc, est, offs, used = O.index_load(idx)
+    assert tu == len(d) and tc == len(st) - len(idx) and len(offs) == 20
+    rs = S.ReadSeeker(st, backend=S.HipBackend(ctx))
+    rng = random.Random(2)
+    for _ in range(8):
+        off = rng.randrange(0, len(d)); n = rng.randrange(1, 1 << 20)
+        assert rs.ReadAt(n, off) == d[off:off + n]

@@ -171,7 +171,7 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tpath):
             tj = json.load(open(tpath))
-            kname = {"enc_tiles": "encode_tiles_kernel<true, false>", "dec_exec": "dec_exec2_kernel", "enc_far_build": "far_build_kernel",
+            kname = {"enc_tiles": "encode_tiles_kernel<true, false, %d>" % (2 if args.level == 2 else 1), "dec_exec": "dec_exec2_kernel", "enc_far_build": "far_build_kernel",
                      "dec_parse": "dec_exit_kernel"}.get(dom)
             if tj.get("workload_bytes") == S and args.workload == "text" and kname in tj.get("kernels", {}):
                 traffic = tj["kernels"][kname]["traffic"]

@@ -107,6 +107,22 @@ int64_t mlz_crc(mlz_ctx* ctx, const uint8_t* src, size_t n);
 int mlz_crc_batch_device(mlz_ctx* ctx, void* stream, const uint8_t* d_base, const mlz_block_desc* desc, int n_blocks,
                          uint32_t* d_out);
 
+/* ---- whole-buffer streams (host pointers) ----
+ * mlz_stream_encode: NewWriter(dst, WriterLevel(level), WriterBlockSize(block_size), WriterAddIndex(flag))
+ *   .EncodeBuffer(src) followed by Close() (writer.go:441-563, :854-965, :1051-1126): stream header,
+ *   one 0x02 / 0x01 chunk per block with the masked CRC32C of its uncompressed bytes, EOF chunk, and
+ *   with MLZ_STREAM_ADD_INDEX the seek index (index.go:191-269).  Returns the stream size.
+ * mlz_stream_decode: NewReader(src) read to EOF (reader.go:248-543), MinLZ streams only; CRCs are
+ *   verified unless MLZ_STREAM_IGNORE_CRC (ReaderIgnoreCRC).  Returns the decoded size.
+ * Copies to and from the device overlap the kernels group by group (~256 MiB). */
+#define MLZ_STREAM_ADD_INDEX 1u
+#define MLZ_STREAM_IGNORE_CRC 2u
+int64_t mlz_stream_bound(uint64_t n, uint32_t block_size, uint32_t flags); /* dst_cap that always suffices */
+int64_t mlz_stream_encode(mlz_ctx* ctx, int level, uint32_t block_size, uint32_t flags, const uint8_t* src, size_t n, uint8_t* dst,
+                          size_t dst_cap);
+int64_t mlz_stream_decoded_len(const uint8_t* src, size_t n); /* host-only chunk walk: total decoded bytes */
+int64_t mlz_stream_decode(mlz_ctx* ctx, uint32_t flags, const uint8_t* src, size_t n, uint8_t* dst, size_t dst_cap);
+
 /* ---- tuning / introspection (not part of the reference surface) ---- */
 #define MLZ_OPT_DECODE_ALGO 1  /* 0 = parallel (default), 1 = serial one-wave-per-block */
 #define MLZ_OPT_ENCODE_FAR 2   /* 0 = tile-local matches only, 1 = + far matches (default) */

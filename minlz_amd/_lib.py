@@ -14,7 +14,8 @@ SYMBOLS = [
     "mlz_init", "mlz_destroy", "mlz_last_error", "mlz_version", "mlz_device_name", "mlz_max_encoded_len",
     "mlz_decoded_len", "mlz_encode", "mlz_decode", "mlz_encode_block", "mlz_decode_block", "mlz_encode_batch",
     "mlz_decode_batch", "mlz_encode_batch_device", "mlz_decode_batch_device", "mlz_set_option", "mlz_get_timers",
-    "mlz_timer_name", "mlz_crc", "mlz_crc_batch_device",
+    "mlz_timer_name", "mlz_crc", "mlz_crc_batch_device", "mlz_stream_bound", "mlz_stream_encode", "mlz_stream_decoded_len",
+    "mlz_stream_decode",
 ]
 
 
@@ -55,5 +56,10 @@ def lib():
     L.mlz_timer_name.argtypes = [i32]; L.mlz_timer_name.restype = C.c_char_p
     L.mlz_crc.argtypes = [vp, vp, sz]; L.mlz_crc.restype = i64
     L.mlz_crc_batch_device.argtypes = [vp, vp, vp, C.POINTER(BlockDesc), i32, vp]; L.mlz_crc_batch_device.restype = i32
+    u32, u64 = C.c_uint32, C.c_uint64
+    L.mlz_stream_bound.argtypes = [u64, u32, u32]; L.mlz_stream_bound.restype = i64
+    L.mlz_stream_encode.argtypes = [vp, i32, u32, u32, vp, sz, vp, sz]; L.mlz_stream_encode.restype = i64
+    L.mlz_stream_decoded_len.argtypes = [vp, sz]; L.mlz_stream_decoded_len.restype = i64
+    L.mlz_stream_decode.argtypes = [vp, u32, vp, sz, vp, sz]; L.mlz_stream_decode.restype = i64
     _lib = L
     return L

@@ -280,3 +280,35 @@ def decode_batch(blocks, ctx=None):
             _raise(ol[i], ctx)
         res.append(outs[i][:ol[i]].tobytes())
     return res
+
+
+STREAM_ADD_INDEX, STREAM_IGNORE_CRC = 1, 2
+
+
+def stream_encode(src, level=LevelFastest, block_size=2 << 20, add_index=False, ctx=None):
+    """mlz_stream_encode: NewWriter(...).EncodeBuffer(src) + Close() in one call -> the .mz stream bytes."""
+    ctx = ctx or default_context()
+    a = _np(src)
+    flags = STREAM_ADD_INDEX if add_index else 0
+    cap = _lib.lib().mlz_stream_bound(a.size, block_size, flags)
+    if cap < 0:
+        _raise(cap, ctx)
+    out = np.empty(cap, dtype=np.uint8)
+    r = _lib.lib().mlz_stream_encode(ctx.handle, level, block_size, flags, _ptr(a), a.size, out.ctypes.data, out.size)
+    if r < 0:
+        _raise(r, ctx)
+    return out[:r].tobytes()
+
+
+def stream_decode(src, ignore_crc=False, ctx=None):
+    """mlz_stream_decode: NewReader(src) read to EOF -> decoded bytes."""
+    ctx = ctx or default_context()
+    a = _np(src)
+    n = _lib.lib().mlz_stream_decoded_len(_ptr(a), a.size)
+    if n < 0:
+        _raise(n, ctx)
+    out = np.empty(max(n, 1), dtype=np.uint8)
+    r = _lib.lib().mlz_stream_decode(ctx.handle, STREAM_IGNORE_CRC if ignore_crc else 0, _ptr(a), a.size, out.ctypes.data, n)
+    if r < 0:
+        _raise(r, ctx)
+    return out[:r].tobytes()

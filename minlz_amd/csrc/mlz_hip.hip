@@ -74,6 +74,11 @@ struct mlz_ctx {
     DevBuf d_dec;
     // host-pointer staging
     DevBuf d_in, d_out, d_len, d_crc;
+    // stream calls: copy-in / copy-out streams, event pool, pinned result buffer
+    hipStream_t s_in = nullptr, s_out = nullptr;
+    std::vector<hipEvent_t> evpool;
+    void* pinned2 = nullptr;
+    size_t pinned2_cap = 0;
     // options
     int decode_algo = 0;
     int encode_far = 1;
@@ -451,6 +456,10 @@ void mlz_destroy(mlz_ctx* c) {
     for (DevBuf* b : {&c->d_crc, &c->d_prof, &c->d_blocks, &c->d_tile_block, &c->d_seg_block, &c->d_scratch, &c->d_tile_size, &c->d_tile_out, &c->d_flags, &c->d_far, &c->d_dummy, &c->d_dec, &c->d_in, &c->d_out, &c->d_len})
         b->release();
     if (c->pinned) (void)hipHostFree(c->pinned);
+    if (c->pinned2) (void)hipHostFree(c->pinned2);
+    if (c->s_in) (void)hipStreamDestroy(c->s_in);
+    if (c->s_out) (void)hipStreamDestroy(c->s_out);
+    for (hipEvent_t e : c->evpool) (void)hipEventDestroy(e);
     for (int i = 0; i < T_COUNT; i++)
         for (int k = 0; k < 2; k++)
             if (c->ev[i][k]) (void)hipEventDestroy(c->ev[i][k]);
@@ -631,3 +640,5 @@ int64_t mlz_crc(mlz_ctx* c, const uint8_t* src, size_t n) {
 }
 
 }  // extern "C"
+
+#include "mlz_stream.hip.inc"

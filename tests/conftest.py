@@ -3,6 +3,11 @@ import sys
 
 import pytest
 
+try:  # PyTorch bundles its own HIP runtime: load it before libminlz_hip.so pulls in /opt/rocm's, whatever the test order
+    import torch  # noqa: F401
+except Exception:  # pragma: no cover
+    torch = None
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

@@ -75,3 +75,18 @@ def test_init_without_gpu_fails_loudly(lib):
     import minlz_amd as mz
     with pytest.raises(mz.ErrHIP):
         mz.Context(0)
+
+
+def test_stream_decoded_len_is_host_only():
+    # mlz_stream_decoded_len walks the chunks on the host (no device call): usable without a GPU
+    import oracle as O
+    from minlz_amd import synth
+    L = _lib.lib()
+    d = synth.text_like(3_000_000, 4).tobytes()
+    st = O.stream_encode(d, 1, 1 << 20, add_index=True)
+    import numpy as np
+    a = np.frombuffer(st, dtype=np.uint8)
+    assert L.mlz_stream_decoded_len(a.ctypes.data, a.size) == len(d)
+    assert L.mlz_stream_decoded_len(a.ctypes.data, a.size // 2) == -1          # ErrCorrupt: truncated
+    assert L.mlz_stream_bound(len(d), 1 << 20, 1) >= len(st)
+    assert L.mlz_stream_bound(len(d), 1000, 0) < 0

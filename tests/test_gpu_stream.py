@@ -73,3 +73,48 @@ def test_index_and_read_seeker_on_device(ctx):
     for _ in range(8):
         off = rng.randrange(0, len(d)); n = rng.randrange(1, 1 << 20)
         assert rs.ReadAt(n, off) == d[off:off + n]
+
+
+@pytest.mark.parametrize("level,bs", [(1, 1 << 20), (2, 8 << 20), (0, 64 << 10), (-1, 256 << 10)])
+def test_stream_abi_matches_writer_mirror(ctx, level, bs):
+    # mlz_stream_encode (C++ host code in the library) == the Python Writer mirror over the same device blocks,
+    # with and without the seek index; both decode with the reference Reader's restatement and with mlz_stream_decode
+    for d in (synth.text_like(20_000_000, 31).tobytes(), synth.random_bytes(300000).tobytes(), b"", b"x", synth.json_like(3 << 20).tobytes()):
+        for add_index in (False, True):
+            st = mz.stream_encode(d, level, bs, add_index, ctx)
+            w = io.BytesIO()
+            wr = S.Writer(w, level=level, block_size=bs, concurrency=7, backend=S.HipBackend(ctx), add_index=add_index)
+            wr.EncodeBuffer(d)
+            wr.Close()
+            assert st == w.getvalue(), (len(d), add_index)
+            assert O.stream_decode(st, len(d)) == d
+            assert mz.stream_decode(st, ctx=ctx) == d
+    # reference-algorithm streams (oracle writer) decode through the ABI as well
+    d = synth.text_like(9_000_000, 5).tobytes()
+    for lv in (0, 1, 2, 3):
+        assert mz.stream_decode(O.stream_encode(d, lv, 1 << 20, add_index=True), ctx=ctx) == d
+
+
+def test_stream_abi_errors(ctx):
+    d = synth.text_like(3_000_000, 9).tobytes()
+    st = bytearray(mz.stream_encode(d, 1, 1 << 20, True, ctx))
+    bad = bytearray(st); bad[16] ^= 0x40                     # inside the first chunk's CRC
+    with pytest.raises(mz.ErrCRC):
+        mz.stream_decode(bytes(bad), ctx=ctx)
+    assert mz.stream_decode(bytes(bad), ignore_crc=True, ctx=ctx) == d    # ReaderIgnoreCRC
+    bad = bytearray(st); bad[40] ^= 0xff                     # token bytes: corrupt data or CRC mismatch
+    with pytest.raises((mz.ErrCorrupt, mz.ErrCRC)):
+        mz.stream_decode(bytes(bad), ctx=ctx)
+    with pytest.raises(mz.ErrCorrupt):
+        mz.stream_decode(bytes(st[:len(st) // 2]), ctx=ctx)  # truncated inside a chunk
+    with pytest.raises(mz.ErrCorrupt):
+        mz.stream_decode(bytes(st[10:]), ctx=ctx)            # no stream header
+    with pytest.raises(mz.ErrUnsupported):
+        mz.stream_decode(bytes.fromhex("ff060000734e61507059"), ctx=ctx)  # Snappy stream identifier
+    with pytest.raises(mz.MinLZError):
+        mz.stream_encode(d, 1, 1000, False, ctx)             # block size below 4 KiB (writer.go:1238-1246)
+    with pytest.raises(mz.ErrInvalidLevel):
+        mz.stream_encode(d, 3, 1 << 20, False, ctx)
+    # framing KAT (minlz_test.go:1120-1134)
+    kat = bytes.fromhex("ff0600004d696e4c7a02") + b"\x01\x08\x00\x00" + b"\x68\x10\xe6\xb6" + b"abcd" + b"\x20\x00\x00\x00"
+    assert mz.stream_decode(kat, ctx=ctx) == b"abcd"

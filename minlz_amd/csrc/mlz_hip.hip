@@ -322,7 +322,7 @@ int decode_parallel(mlz_ctx* c, hipStream_t st, const uint8_t* d_src, uint8_t* d
         Timer t(c, T_DEC_INDEX, st);
         if (segs)
             hipLaunchKernelGGL(dec_index_a_kernel, dim3(segs), dim3(kSegThreads), kIndexLds, st, d_src, blocks, seg_block, dec, seg_entry, seg_out, seg_last, rexit_tab);
-        hipLaunchKernelGGL(dec_index_b_kernel, dim3((n + 63) / 64), dim3(64), 0, st, blocks, dec, seg_out, seg_last, seg_entry, n);
+        hipLaunchKernelGGL(dec_index_b_kernel, dim3(n), dim3(64), 0, st, blocks, dec, seg_out, seg_last, seg_entry, n);
         if (segs)
             hipLaunchKernelGGL(dec_index_c_kernel, dim3(segs), dim3(kSegThreads), kIndexLds, st, d_src, blocks, seg_block, dec, seg_entry, seg_out, seg_last,
                                tile_start, tok_mask, chunk_d, chunk_rep, rexit_tab);

@@ -312,7 +312,7 @@ int decode_parallel(mlz_ctx* c, hipStream_t st, const uint8_t* d_src, uint8_t* d
         HIPCHK(c, hipMemsetAsync(ws + o_done, 0, o_ticket + 256 - o_done, st));
         hipLaunchKernelGGL(dec_header_kernel, dim3((n + 63) / 64), dim3(64), 0, st, d_src, blocks, dec, n, raw_body ? 1 : 0);
         if (segs)
-            hipLaunchKernelGGL(dec_exit_kernel, dim3(segs), dim3(kSegThreads), kExitLds, st, d_src, blocks, seg_block, dec, exit_tab, rexit_tab);
+            hipLaunchKernelGGL(dec_exit_kernel, dim3(segs), dim3(kExitThreads), kExitLds, st, d_src, blocks, seg_block, dec, exit_tab, rexit_tab);
     }
     {
         Timer t(c, T_DEC_CHAIN, st);

@@ -275,7 +275,10 @@ int decode_parallel(mlz_ctx* c, hipStream_t st, const uint8_t* d_src, uint8_t* d
     const size_t o_mask = o_tstart + al(size_t(tiles) * sizeof(TileStart));
     const size_t o_cd = o_mask + al(size_t(segs) * kSegThreads * 8);
     const size_t o_cr = o_cd + al(size_t(segs) * kSegThreads * 4);
-    const size_t o_order = o_cr + al(size_t(segs) * kSegThreads * 4);
+    const size_t o_rout = o_cr + al(size_t(segs) * kSegThreads * 4);
+    const size_t o_rlast = o_rout + al(size_t(segs) * kSegThreads * 4);
+    const size_t o_rentry = o_rlast + al(size_t(segs) * kSegThreads * 4);
+    const size_t o_order = o_rentry + al(size_t(segs) * kSegThreads * 2);
     const size_t o_done = o_order + al(size_t(tiles) * 4);
     const size_t o_ticket = o_done + al(size_t(tiles) * 4);
     const size_t total = o_ticket + 256;
@@ -291,6 +294,9 @@ int decode_parallel(mlz_ctx* c, hipStream_t st, const uint8_t* d_src, uint8_t* d
     uint64_t* tok_mask = reinterpret_cast<uint64_t*>(ws + o_mask);
     uint32_t* chunk_d = reinterpret_cast<uint32_t*>(ws + o_cd);
     uint32_t* chunk_rep = reinterpret_cast<uint32_t*>(ws + o_cr);
+    uint32_t* reg_out = reinterpret_cast<uint32_t*>(ws + o_rout);
+    uint32_t* reg_last = reinterpret_cast<uint32_t*>(ws + o_rlast);
+    uint16_t* reg_entry = reinterpret_cast<uint16_t*>(ws + o_rentry);
     uint32_t* order = reinterpret_cast<uint32_t*>(ws + o_order);
     uint32_t* tile_done = reinterpret_cast<uint32_t*>(ws + o_done);
     uint32_t* ticket = reinterpret_cast<uint32_t*>(ws + o_ticket);
@@ -321,11 +327,11 @@ int decode_parallel(mlz_ctx* c, hipStream_t st, const uint8_t* d_src, uint8_t* d
     {
         Timer t(c, T_DEC_INDEX, st);
         if (segs)
-            hipLaunchKernelGGL(dec_index_a_kernel, dim3(segs), dim3(kSegThreads), kIndexLds, st, d_src, blocks, seg_block, dec, seg_entry, seg_out, seg_last, rexit_tab);
+            hipLaunchKernelGGL(dec_index_a_kernel, dim3(segs), dim3(kSegThreads), kIndexLds, st, d_src, blocks, seg_block, dec, seg_entry, seg_out, seg_last, rexit_tab, reg_out, reg_last, reg_entry);
         hipLaunchKernelGGL(dec_index_b_kernel, dim3(n), dim3(64), 0, st, blocks, dec, seg_out, seg_last, seg_entry, n);
         if (segs)
             hipLaunchKernelGGL(dec_index_c_kernel, dim3(segs), dim3(kSegThreads), kIndexLds, st, d_src, blocks, seg_block, dec, seg_entry, seg_out, seg_last,
-                               tile_start, tok_mask, chunk_d, chunk_rep, rexit_tab);
+                               tile_start, tok_mask, chunk_d, chunk_rep, reg_out, reg_last, reg_entry);
         if (tiles) hipLaunchKernelGGL(dec_schedule_kernel, dim3(1), dim3(256), 0, st, blocks, tile_block, dec, order, tiles);
     }
     {

@@ -129,6 +129,34 @@ MLZ_HD Emit plan_emit(uint32_t lits, uint32_t off, uint32_t len, bool is_repeat)
     return e;
 }
 
+// plan_emit for the common tokens: no length-extension bytes anywhere (pending literals <= 29, repeat
+// length <= 29, copy length <= 64).  About a third of the instructions of the general builder; the
+// encoder takes it when every token of a batch qualifies (plan_emit_is_short), byte-identical result.
+MLZ_HD bool plan_emit_is_short(uint32_t lits, uint32_t len, bool is_repeat) {
+    return lits <= 29 && (is_repeat ? len <= 29 : len <= 64);
+}
+MLZ_HD Emit plan_emit_short(uint32_t lits, uint32_t off, uint32_t len, bool is_repeat) {
+    const bool f2 = !is_repeat && lits > 0 && lits <= 4 && off >= kMinCopy2Offset && off <= kMaxCopy2Offset;
+    const bool f3 = !is_repeat && lits > 0 && lits <= 3 && off > kMaxCopy2Offset;
+    const Hdr none{0, 0};
+    const Hdr lh{uint64_t((lits - 1) << 3), lits ? 1u : 0u};
+    const uint32_t l4 = len - 4;
+    const uint32_t o2 = (off - kMinCopy2Offset) & 0xffff;
+    // repeat (len <= 29), or the <= 53-byte tail of a fused copy2 that is longer than 11
+    const uint32_t rn = is_repeat ? len : len - 11;
+    const Hdr rh = rn <= 29 ? Hdr{uint64_t(((rn - 1) << 3) | 4), 1} : Hdr{uint64_t((29u << 3) | 4) | (uint64_t(rn - 30) << 8), 2};
+    const uint32_t o1 = ((off - 1) << 6) & 0xffff;
+    const Hdr c1 = len < 19 ? Hdr{uint64_t(o1 | (l4 << 2) | 1), 2} : Hdr{uint64_t(o1 | (15 << 2) | 1) | (uint64_t(len - 18) << 16), 3};
+    const Hdr c2{uint64_t((l4 << 2) | 2) | (uint64_t(o2) << 8), 3};
+    const Hdr c3{uint64_t(((off - kMinCopy3Offset) << 11) | 7u | ((f3 ? lits : 0) << 3) | (l4 << 5)), 4};
+    const Hdr f2h{uint64_t(3u | ((l4 > 7 ? 7u : l4) << 5) | (((lits - 1) & 3) << 3)) | (uint64_t(o2) << 8), 3};
+    Emit e;
+    e.pre = hdr_sel(f2, f2h, hdr_sel(f3, c3, lh));
+    const Hdr plain = hdr_sel(off > kMaxCopy2Offset, c3, hdr_sel(off <= kMaxCopy1Offset, c1, c2));
+    e.post = hdr_sel(is_repeat, rh, hdr_sel(f2, hdr_sel(len > 11, rh, none), hdr_sel(f3, none, plain)));
+    return e;
+}
+
 MLZ_HD uint32_t put_uvarint(uint8_t* dst, uint64_t v) {
     uint32_t i = 0;
     while (v >= 0x80) { dst[i++] = uint8_t(v) | 0x80; v >>= 7; }

@@ -1,5 +1,10 @@
 // mlz_kernels.h — device-side data structures shared between the kernels and the host API.
 #pragma once
+// Phase cycle counters / per-tile timelines inside the kernels (debug options 4, 5, 7) are compiled in only
+// with -DMLZ_PROFILE=1 (tools/exp_build.sh); in the product build every hook folds away.
+#ifndef MLZ_PROFILE
+#define MLZ_PROFILE 0
+#endif
 #include <stdint.h>
 
 namespace mlz {

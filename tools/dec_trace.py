@@ -1,4 +1,7 @@
 """Per-tile timeline of the exec pass (debug option 7): start / ready / loop end / published, by level."""
+# Needs a library built with -DMLZ_PROFILE=1: bash tools/build_profile_lib.sh, then run with
+# MINLZ_HIP_LIB=$PWD/build_var/libminlz_hip_prof.so (the product build compiles the counters out).
+
 import os, sys, ctypes as C
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

@@ -1,3 +1,5 @@
+# Needs a library built with -DMLZ_PROFILE=1: bash tools/build_profile_lib.sh, then run with
+# MINLZ_HIP_LIB=$PWD/build_var/libminlz_hip_prof.so (the product build compiles the counters out).
 import os, sys, ctypes as C
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import numpy as np, torch

@@ -22,6 +22,7 @@
 #include "mlz_decode_serial.hip.inc"
 #include "mlz_decode.hip.inc"
 #include "mlz_decode_exec.hip.inc"
+#include "mlz_decode_general.hip.inc"
 #include "mlz_crc.hip.inc"
 
 using namespace mlz;
@@ -71,7 +72,9 @@ struct mlz_ctx {
     // encode workspace
     DevBuf d_scratch, d_tile_size, d_tile_out, d_flags, d_far, d_dummy;
     // decode workspace
-    DevBuf d_dec;
+    DevBuf d_dec, d_idx;
+    int general_algo = 0;  // 0 = pointer-jumping pass for general blocks, 1 = tile chain in the exec pass
+    int n_cus = 0;
     // host-pointer staging
     DevBuf d_in, d_out, d_len, d_crc;
     // stream calls: copy-in / copy-out streams, event pool, pinned result buffer
@@ -281,7 +284,8 @@ int decode_parallel(mlz_ctx* c, hipStream_t st, const uint8_t* d_src, uint8_t* d
     const size_t o_order = o_rentry + al(size_t(segs) * kSegThreads * 2);
     const size_t o_done = o_order + al(size_t(tiles) * 4);
     const size_t o_ticket = o_done + al(size_t(tiles) * 4);
-    const size_t total = o_ticket + 256;
+    const size_t o_gen = o_ticket + 256;  // GenCtl (zeroed with the flags)
+    const size_t total = o_gen + al(sizeof(GenCtl));
     HIPCHK(c, c->d_dec.ensure(total));
     uint8_t* ws = c->d_dec.as<uint8_t>();
     DecBlock* dec = reinterpret_cast<DecBlock*>(ws + o_dec);
@@ -300,6 +304,12 @@ int decode_parallel(mlz_ctx* c, hipStream_t st, const uint8_t* d_src, uint8_t* d
     uint32_t* order = reinterpret_cast<uint32_t*>(ws + o_order);
     uint32_t* tile_done = reinterpret_cast<uint32_t*>(ws + o_done);
     uint32_t* ticket = reinterpret_cast<uint32_t*>(ws + o_ticket);
+    GenCtl* gen = reinterpret_cast<GenCtl*>(ws + o_gen);
+    // General blocks (streams of other encoders) go through the pointer-jumping pass when its 4 B per output
+    // byte of workspace is affordable (<= 4 GiB) and the current exec pass is in use.
+    const size_t idx_bytes = (size_t(tiles) << kTileLog) * 4;
+    const bool jump = c->general_algo == 0 && c->decode_algo == 0 && tiles > 0 && idx_bytes <= (size_t(4) << 30);
+    if (jump) HIPCHK(c, c->d_idx.ensure(idx_bytes));
     const BlockInfo* blocks = c->d_blocks.as<BlockInfo>();
     const uint32_t* tile_block = c->d_tile_block.as<uint32_t>();
     const uint32_t* seg_block = c->d_seg_block.as<uint32_t>();
@@ -315,7 +325,7 @@ int decode_parallel(mlz_ctx* c, hipStream_t st, const uint8_t* d_src, uint8_t* d
     {
         Timer t(c, T_DEC_PARSE, st);
         if (segs) HIPCHK(c, hipMemsetAsync(seg_entry, 0xff, size_t(segs) * 4, st));
-        HIPCHK(c, hipMemsetAsync(ws + o_done, 0, o_ticket + 256 - o_done, st));
+        HIPCHK(c, hipMemsetAsync(ws + o_done, 0, total - o_done, st));
         hipLaunchKernelGGL(dec_header_kernel, dim3((n + 63) / 64), dim3(64), 0, st, d_src, blocks, dec, n, raw_body ? 1 : 0);
         if (segs)
             hipLaunchKernelGGL(dec_exit_kernel, dim3(segs), dim3(kExitThreads), kExitLds, st, d_src, blocks, seg_block, dec, exit_tab, rexit_tab);
@@ -331,7 +341,7 @@ int decode_parallel(mlz_ctx* c, hipStream_t st, const uint8_t* d_src, uint8_t* d
         hipLaunchKernelGGL(dec_index_b_kernel, dim3(n), dim3(64), 0, st, blocks, dec, seg_out, seg_last, seg_entry, n);
         if (segs)
             hipLaunchKernelGGL(dec_index_c_kernel, dim3(segs), dim3(kSegThreads), kIndexLds, st, d_src, blocks, seg_block, dec, seg_entry, seg_out, seg_last,
-                               tile_start, tok_mask, chunk_d, chunk_rep, reg_out, reg_last, reg_entry);
+                               tile_start, tok_mask, chunk_d, chunk_rep, reg_out, reg_last, reg_entry, jump ? &gen->n_general : nullptr);
         if (tiles) hipLaunchKernelGGL(dec_schedule_kernel, dim3(1), dim3(256), 0, st, blocks, tile_block, dec, order, tiles);
     }
     {
@@ -343,6 +353,9 @@ int decode_parallel(mlz_ctx* c, hipStream_t st, const uint8_t* d_src, uint8_t* d
         else if (tiles)
             hipLaunchKernelGGL(dec_exec2_kernel, dim3(tiles), dim3(kExecThreads), kExecLds, st, d_src, d_dst, blocks, tile_block, dec, tile_start, tok_mask,
                                chunk_d, chunk_rep, order, tile_done, ticket, tiles, prof);
+        if (jump && segs)  // returns at once unless D3c flagged a general block
+            hipLaunchKernelGGL(dec_general_kernel, dim3(c->n_cus), dim3(kGenThreads), 0, st, d_src, d_dst, blocks, seg_block, tile_block, dec, tok_mask,
+                               chunk_d, chunk_rep, c->d_idx.as<uint32_t>(), gen, segs, tiles);
         hipLaunchKernelGGL(dec_finish_kernel, dim3((n + 63) / 64), dim3(64), 0, st, dec, d_out_len, n, c->debug_status);
     }
     HIPCHK(c, hipGetLastError());
@@ -445,7 +458,11 @@ int mlz_init(int device, mlz_ctx** out) {
     mlz_ctx* c = new mlz_ctx();
     c->device = device;
     hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->dev_name = std::string(prop.name) + " (" + prop.gcnArchName + ")";
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) {
+        c->dev_name = std::string(prop.name) + " (" + prop.gcnArchName + ")";
+        c->n_cus = prop.multiProcessorCount;
+    }
+    if (c->n_cus <= 0) c->n_cus = 64;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return -MLZ_ERR_HIP; }
     if (hipEventCreateWithFlags(&c->upload_done, hipEventDisableTiming) != hipSuccess) { delete c; return -MLZ_ERR_HIP; }
     for (int i = 0; i < T_COUNT; i++)
@@ -459,7 +476,7 @@ void mlz_destroy(mlz_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
-    for (DevBuf* b : {&c->d_crc, &c->d_prof, &c->d_blocks, &c->d_tile_block, &c->d_seg_block, &c->d_scratch, &c->d_tile_size, &c->d_tile_out, &c->d_flags, &c->d_far, &c->d_dummy, &c->d_dec, &c->d_in, &c->d_out, &c->d_len})
+    for (DevBuf* b : {&c->d_crc, &c->d_prof, &c->d_blocks, &c->d_tile_block, &c->d_seg_block, &c->d_scratch, &c->d_tile_size, &c->d_tile_out, &c->d_flags, &c->d_far, &c->d_dummy, &c->d_dec, &c->d_idx, &c->d_in, &c->d_out, &c->d_len})
         b->release();
     if (c->pinned) (void)hipHostFree(c->pinned);
     if (c->pinned2) (void)hipHostFree(c->pinned2);
@@ -582,6 +599,7 @@ int mlz_set_option(mlz_ctx* c, int opt, int64_t value) {
     switch (opt) {
     case MLZ_OPT_DECODE_ALGO: c->decode_algo = int(value); return 0;
     case MLZ_OPT_ENCODE_FAR: c->encode_far = int(value); return 0;
+    case 8: c->general_algo = int(value); return 0;  // 0 = pointer-jumping pass for general blocks (default), 1 = tile chain
     case 6: c->encode_staged = int(value); return 0;  // tuning: 0 = in-place tile bytes (default), 1 = LDS-staged tile bytes, 3 = software-pipelined variant
     case 3: c->debug_status = int(value); return 0;  // debug: report failure sites in the error code
     case 4: {  // debug: per-phase cycle counters (16 x u64: 0-7 encode, 8-15 decode)

@@ -185,3 +185,42 @@ def test_decode_batch(ctx):
     blocks = [synth.text_like(300000, s).tobytes() for s in range(5)] + [b"", b"abc", synth.random_bytes(70000).tobytes()]
     encs = [O.encode(b, 1) for b in blocks]
     assert mz.decode_batch(encs, ctx) == blocks
+
+
+def test_general_block_paths_agree(ctx):
+    # Streams of other encoders ("general" blocks) have two decode paths: byte-granular pointer jumping (default)
+    # and the tile chain (option 8 = 1).  Both must give the oracle's bytes and the oracle's verdicts.
+    import numpy as np
+    items = [synth.text_like(3 << 20, 77), synth.json_like(1 << 20), synth.pattern("off2", 300000), synth.pattern("zeros", 200000),
+             synth.large_offset(3 << 20, 1 << 20)]
+    encs = [O.encode(d, lv) for d in items for lv in (1, 2, 3)]
+    want = [d.tobytes() for d in items for _ in (1, 2, 3)]
+    rng = np.random.default_rng(3)
+    mutated = []
+    for e in encs[:6]:
+        for _ in range(6):
+            m = bytearray(e)
+            pos = int(rng.integers(4, len(m)))
+            m[pos] ^= int(rng.integers(1, 256))
+            mutated.append(bytes(m))
+    results = {}
+    for algo in (0, 1):
+        ctx.set_option(8, algo)
+        try:
+            assert mz.decode_batch(encs, ctx) == want
+            verdicts = []
+            for m in mutated:
+                try:
+                    verdicts.append(("ok", mz.Decode(m, ctx)))
+                except mz.MinLZError as ex:
+                    verdicts.append(("err", type(ex).__name__))
+            results[algo] = verdicts
+        finally:
+            ctx.set_option(8, 0)
+    assert results[0] == results[1]
+    for m, v in zip(mutated, results[0]):
+        try:
+            o = ("ok", O.decode(m))
+        except O.OracleError:
+            o = ("err", "ErrCorrupt")
+        assert (v[0] == o[0]) and (v[0] == "err" or v[1] == o[1])

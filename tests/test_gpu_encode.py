@@ -147,3 +147,57 @@ def test_level_balanced_roundtrip(ctx):
     d = synth.json_like(2 << 20)
     enc = roundtrip(d, ctx, level=2)
     assert len(enc) < d.size // 2
+
+
+def test_device_batch_unaligned_offsets(ctx):
+    # device-resident API with block offsets of every alignment (the kernels take 16-byte fast paths only when they can)
+    import torch
+    from minlz_amd._lib import BlockDesc
+    dev = torch.device("cuda", 0)
+    parts = [synth.text_like(700_001, 3), synth.json_like(300_003), synth.random_bytes(70_001), synth.pattern("zeros", 100_000), synth.text_like(33, 5)]
+    offs, cur = [], 1
+    for p in parts:
+        offs.append(cur)
+        cur += p.size + 3          # 1, +odd strides: every residue mod 16 shows up
+    host = np.zeros(cur + 64, dtype=np.uint8)
+    for o, p in zip(offs, parts):
+        host[o:o + p.size] = p
+    src = torch.from_numpy(host).to(dev)
+    ecap = [mz.MaxEncodedLen(p.size) for p in parts]
+    eoffs, ecur = [], 5
+    for c in ecap:
+        eoffs.append(ecur)
+        ecur += c + 7
+    enc = torch.zeros(ecur + 64, dtype=torch.uint8, device=dev)
+    elen = torch.zeros(len(parts), dtype=torch.int64, device=dev)
+    st = torch.cuda.current_stream(dev).cuda_stream
+    edesc = [BlockDesc(o, p.size, eo, c) for o, p, eo, c in zip(offs, parts, eoffs, ecap)]
+    ctx.encode_batch_device(st, 1, src.data_ptr(), enc.data_ptr(), edesc, elen.data_ptr())
+    torch.cuda.synchronize()
+    lens = elen.cpu().tolist()
+    assert all(l > 0 for l in lens)
+    ehost = enc.cpu().numpy()
+    for p, eo, l in zip(parts, eoffs, lens):
+        assert O.decode(ehost[eo:eo + l].tobytes()) == p.tobytes()
+    # nothing outside the blocks' output ranges was touched
+    mask = np.ones(ehost.size, dtype=bool)
+    for eo, c in zip(eoffs, ecap):
+        mask[eo:eo + c] = False
+    assert not ehost[mask].any()
+    # decode back to odd offsets, with guard bytes between the blocks
+    doffs, dcur = [], 3
+    for p in parts:
+        doffs.append(dcur)
+        dcur += p.size + 5
+    dec = torch.full((dcur + 64,), 0xA5, dtype=torch.uint8, device=dev)
+    dlen = torch.zeros(len(parts), dtype=torch.int64, device=dev)
+    ddesc = [BlockDesc(eo, l, do, p.size) for eo, l, do, p in zip(eoffs, lens, doffs, parts)]
+    ctx.decode_batch_device(st, enc.data_ptr(), dec.data_ptr(), ddesc, dlen.data_ptr())
+    torch.cuda.synchronize()
+    assert dlen.cpu().tolist() == [p.size for p in parts]
+    dhost = dec.cpu().numpy()
+    gmask = np.ones(dhost.size, dtype=bool)
+    for p, do in zip(parts, doffs):
+        assert dhost[do:do + p.size].tobytes() == p.tobytes()
+        gmask[do:do + p.size] = False
+    assert (dhost[gmask] == 0xA5).all()

@@ -218,7 +218,7 @@ int encode_device_locked(mlz_ctx* c, hipStream_t st, int level, const uint8_t* d
 #define MLZ_LAUNCH_ENC1(F, S, LV, LDS)                                                                                                          \
     hipLaunchKernelGGL((encode_tiles_kernel<F, S, LV>), dim3(tiles), dim3(64), LDS, st, d_src, blocks, tile_block, c->d_scratch.as<uint8_t>(), \
                        c->d_tile_size.as<uint32_t>(), ftab, epochs, prof)
-#define MLZ_LAUNCH_ENC(F, S, LDS) do { if (F && level == MLZ_LEVEL_BALANCED) MLZ_LAUNCH_ENC1(F, S, 2, LDS); else MLZ_LAUNCH_ENC1(F, S, 1, LDS); } while (0)
+#define MLZ_LAUNCH_ENC(F, S, LDS) do { if (F && level == MLZ_LEVEL_BALANCED) MLZ_LAUNCH_ENC1(F, S, 2, (S ? LDS : kEncLdsTwoWay)); else MLZ_LAUNCH_ENC1(F, S, 1, LDS); } while (0)
             if (c->encode_staged == 1) { if (far) MLZ_LAUNCH_ENC(true, true, kEncLdsStaged); else MLZ_LAUNCH_ENC(false, true, kEncLdsStaged); }
             else if (c->encode_staged == 4) {  // experiment: producer/consumer pair of waves per tile (mlz_encode_pc.hip.inc)
                 if (!c->d_dummy.p) {

@@ -14,9 +14,9 @@ pytestmark = pytest.mark.gpu
 
 # Stated ratio tolerances (DESIGN.md "Ratio"), on text-like and JSON-like 8 MiB blocks:
 #   LevelFastest : C_gpu(1) <= RATIO_TOL    * C_oracle(L1)   (measured 1.03 / 1.05)
-#   LevelBalanced: C_gpu(2) <= RATIO_TOL_L2 * C_oracle(L2)   (measured 1.20 / 1.13), and C_gpu(2) <= C_gpu(1)
+#   LevelBalanced: C_gpu(2) <= RATIO_TOL_L2 * C_oracle(L2)   (measured 1.16 / 1.12), and C_gpu(2) <= C_gpu(1)
 RATIO_TOL = 1.15
-RATIO_TOL_L2 = 1.25
+RATIO_TOL_L2 = 1.20
 
 
 def roundtrip(d, ctx, level=1):
@@ -147,6 +147,18 @@ def test_level_balanced_roundtrip(ctx):
     d = synth.json_like(2 << 20)
     enc = roundtrip(d, ctx, level=2)
     assert len(enc) < d.size // 2
+    # level-2 streams carry copies from the preceding tile (pre-loaded near table): device decode, both exec passes
+    t = synth.text_like(3_000_000, 5)
+    e = roundtrip(t, ctx, level=2)
+    for algo in (0, 3, 1):
+        ctx.set_option(mz.OPT_DECODE_ALGO, algo)
+        try:
+            assert mz.Decode(e, ctx) == t.tobytes()
+        finally:
+            ctx.set_option(mz.OPT_DECODE_ALGO, 0)
+    # short blocks: one tile and a bit, tile boundary +- a few bytes
+    for n in (32768, 32769, 32770, 32771, 32775, 65536 + 3, 98304 + 1):
+        roundtrip(t[:n], ctx, level=2)
 
 
 def test_device_batch_unaligned_offsets(ctx):

@@ -33,11 +33,14 @@ typedef struct {
     int ways;         /* near table ways (1 or 2: most recent + previous) */
     int lazy;         /* selection: prefer a match at p+1 that is longer by >= lazy (0 = off) */
     int far_all;      /* probe both epochs for every position */
+    int preseed;      /* near table pre-seeded with up to this many preceding tiles while they have a lower level */
+    int nohole;       /* near matches may read far-copied bytes (the current decoder allows it) */
 } params;
 
 static inline uint64_t ld64(const uint8_t* p) { uint64_t v; memcpy(&v, p, 8); return v; }
 static inline uint32_t ld32(const uint8_t* p) { uint32_t v; memcpy(&v, p, 4); return v; }
 
+#define NOPOS INT32_MIN
 static inline uint32_t hashN(uint64_t v, int bytes, int bits) {
     if (bytes == 4) return ((uint32_t)v * 2654435761u) >> (32 - bits);
     if (bytes == 5) return (uint32_t)(((v << 24) * 889523592379ull) >> (64 - bits));
@@ -95,15 +98,21 @@ size_t model_block(const uint8_t* src, size_t n, const params* P, stats* st) {
         }
     }
     uint8_t* depth = (uint8_t*)calloc(n + 8, 1);
-    uint16_t* table = (uint16_t*)malloc(sizeof(uint16_t) << P->hash_bits);
-    uint16_t* table2 = (uint16_t*)malloc(sizeof(uint16_t) << P->hash_bits);
+    int32_t* table = (int32_t*)malloc(sizeof(int32_t) << P->hash_bits);
+    int32_t* table2 = (int32_t*)malloc(sizeof(int32_t) << P->hash_bits);
     uint32_t* pwtab = P->pw_tiles ? (uint32_t*)malloc(sizeof(uint32_t) << P->pw_bits) : NULL;
     uint8_t* hole = (uint8_t*)malloc(T + 8);
     for (size_t t = 0; t < ntiles; t++) {
         size_t base = t * T, tl = n - base < T ? n - base : T;
         const uint8_t* s = src + base;
-        memset(table, 0, sizeof(uint16_t) << P->hash_bits);
-        memset(table2, 0, sizeof(uint16_t) << P->hash_bits);
+        for (size_t q = 0; q < ((size_t)1 << P->hash_bits); q++) table[q] = table2[q] = NOPOS;
+        long seed_lo = 0;
+        if (P->preseed && P->nlevels) {
+            int mylv0 = tile_level(t, P); long tt = (long)t - 1; int got = 0;
+            while (tt >= 0 && got < P->preseed && tile_level(tt, P) < mylv0) { tt--; got++; }
+            seed_lo = -(long)got * (long)T;
+            for (long q = seed_lo; q < 0; q++) { uint32_t h = hashN(ld64(s + q), P->hash_bytes, P->hash_bits); if (P->ways > 1) table2[P->ways >= 3 ? h >> (P->ways - 2) : h] = table[h]; table[h] = (int32_t)q; }
+        }
         memset(hole, 0, T + 8);
         if (pwtab) {
             memset(pwtab, 0xff, sizeof(uint32_t) << P->pw_bits);
@@ -122,7 +131,7 @@ size_t model_block(const uint8_t* src, size_t n, const params* P, stats* st) {
         while (cur + 8 <= tl) {
             size_t s0 = cur;
             /* phase 1: all lanes look up */
-            uint16_t cand[64]; uint16_t cand2[64]; uint32_t hh[64]; int valid[64];
+            int32_t cand[64]; int32_t cand2[64]; uint32_t hh[64]; int valid[64];
             size_t len_[64], off_[64]; int isrep[64], isfar[64];
             for (int i = 0; i < W; i++) {
                 size_t p = s0 + i;
@@ -131,9 +140,9 @@ size_t model_block(const uint8_t* src, size_t n, const params* P, stats* st) {
                 if (!valid[i]) continue;
                 uint64_t v = ld64(s + p);
                 hh[i] = hashN(v, P->hash_bytes, P->hash_bits);
-                cand[i] = table[hh[i]]; cand2[i] = table2[hh[i]];
+                cand[i] = table[hh[i]]; cand2[i] = table2[P->ways >= 3 ? hh[i] >> (P->ways - 2) : hh[i]];
             }
-            for (int i = 0; i < W; i++) if (valid[i]) { if (P->ways > 1) { uint16_t old = table[hh[i]]; if (old < s0) table2[hh[i]] = old; } table[hh[i]] = (uint16_t)(s0 + i); } /* highest lane wins */
+            for (int i = 0; i < W; i++) if (valid[i]) { if (P->ways > 1) { int32_t old = table[hh[i]]; if (old < (long)s0) table2[P->ways >= 3 ? hh[i] >> (P->ways - 2) : hh[i]] = old; } table[hh[i]] = (int32_t)(s0 + i); } /* highest lane wins */
             for (int i = 0; i < W; i++) {
                 if (!valid[i]) continue;
                 size_t p = s0 + i, maxl = tl - p;
@@ -142,11 +151,11 @@ size_t model_block(const uint8_t* src, size_t n, const params* P, stats* st) {
                     size_t l = mlen(s + p, s + p - rep, maxl);
                     if (l >= 4) { best = l; boff = rep; brep = 1; }
                 }
-                if (cand[i] < p) {
+                if (cand[i] != NOPOS && cand[i] < (long)p) {
                     size_t l = mlen(s + p, s + cand[i], maxl);
                     if (l >= 4 && (!brep || l > best + 1)) { if (!brep || l > best + 1) { best = l; boff = p - cand[i]; brep = 0; } }
                 }
-                if (P->ways > 1 && cand2[i] < p && cand2[i] != cand[i]) {
+                if (P->ways > 1 && cand2[i] != NOPOS && cand2[i] < (long)p && cand2[i] != cand[i]) {
                     size_t l = mlen(s + p, s + cand2[i], maxl);
                     if (l >= 4 && l > best + 1) { best = l; boff = p - cand2[i]; brep = 0; }
                 }
@@ -189,10 +198,10 @@ size_t model_block(const uint8_t* src, size_t n, const params* P, stats* st) {
                 size_t pp = p;
                 if (P->back_ext) {
                     const uint8_t* a = s + pp; const uint8_t* b = f ? src + (base + pp - off) : s + pp - off;
-                    while (pp > next_emit && (f ? (base + pp - off) > 0 : pp - off > 0) && a[-1] == b[-1]) { a--; b--; pp--; L++; }
+                    while (pp > next_emit && (f ? (base + pp - off) > 0 : (long)pp - (long)off > seed_lo) && a[-1] == b[-1]) { a--; b--; pp--; L++; }
                 }
                 /* near matches must not read holes (C1): trim at first hole byte in source */
-                if (!f) {
+                if (!f && !P->nohole && off <= pp) {
                     size_t q = pp - off, k = 0;
                     while (k < L && !hole[q + k]) k++;
                     /* overlapping copies read dest bytes which are non-hole by construction */

@@ -332,7 +332,7 @@ int decode_parallel(mlz_ctx* c, hipStream_t st, const uint8_t* d_src, uint8_t* d
     }
     {
         Timer t(c, T_DEC_CHAIN, st);
-        hipLaunchKernelGGL(dec_chain_kernel, dim3((n + 63) / 64), dim3(64), 0, st, blocks, dec, exit_tab, seg_entry, n);
+        hipLaunchKernelGGL(dec_chain_kernel, dim3(n), dim3(kChainThreads), 0, st, blocks, dec, exit_tab, seg_entry, n);
     }
     {
         Timer t(c, T_DEC_INDEX, st);

@@ -9,7 +9,14 @@ from minlz_amd._lib import BlockDesc
 S = 100_000_000; BLOCK = 8 << 20
 LEVEL = int(os.environ.get("LEVEL", "1"))
 ctx = mz.Context(0)
-host = synth.text_like(S, 1) if os.environ.get("KIND", "text") == "text" else synth.json_like(S)
+KIND = os.environ.get("KIND", "text")
+if KIND == "mixed":  # 32 KiB of noise in every 256 KiB of text: literal runs longer than a token-stream segment
+    host = synth.text_like(S, 1).copy()
+    noise = synth.random_bytes(S // 8)
+    for i, o in enumerate(range(0, S - (256 << 10), 256 << 10)):
+        host[o:o + (32 << 10)] = noise[i * (32 << 10):(i + 1) * (32 << 10)]
+else:
+    host = synth.text_like(S, 1) if KIND == "text" else synth.json_like(S)
 dev = torch.device("cuda", 0)
 src = torch.from_numpy(host).to(dev); nblk = (S + BLOCK - 1) // BLOCK; stride = BLOCK + 256
 enc = torch.empty(nblk * stride, dtype=torch.uint8, device=dev); enc_len = torch.zeros(nblk, dtype=torch.int64, device=dev)

@@ -207,9 +207,8 @@ int encode_device_locked(mlz_ctx* c, hipStream_t st, int level, const uint8_t* d
                 HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(far_build_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 4u << kFarSliceBits));
                 far_attr = true;
             }
-            for (uint32_t lset = 0; lset + 1 < uint32_t(kLevels); lset++)  // level set L builds on level set L-1
-                hipLaunchKernelGGL(far_build_kernel, dim3(kFarSlices, epochs, n), dim3(1024), 4u << kFarSliceBits, st, d_src, blocks,
-                                   c->d_far.as<uint32_t>(), epochs, lset);
+            hipLaunchKernelGGL(far_build_kernel, dim3(kFarSlices, epochs, n), dim3(1024), 4u << kFarSliceBits, st, d_src, blocks,
+                               c->d_far.as<uint32_t>(), epochs);
         }
         {
             Timer t(c, T_ENC_TILES, st);

@@ -132,6 +132,10 @@ int mlz_set_option(mlz_ctx* ctx, int opt, int64_t value);
 #define MLZ_TIMER_ENABLE 100
 int mlz_get_timers(mlz_ctx* ctx, float* ms, int cap); /* returns number of timers written */
 const char* mlz_timer_name(int idx);
+/* Counters of the combining queue behind the single-block host calls (mlz_encode, mlz_encode_block, mlz_decode,
+ * mlz_decode_block): concurrent callers — one goroutine per block in the reference's Writer/Reader, writer.go:501-560,
+ * reader.go:830-859 — are run as one batched launch.  which: 0 = batches run, 1 = requests served. */
+int64_t mlz_get_counter(mlz_ctx* ctx, int which);
 
 #ifdef __cplusplus
 }

@@ -15,7 +15,7 @@ SYMBOLS = [
     "mlz_decoded_len", "mlz_encode", "mlz_decode", "mlz_encode_block", "mlz_decode_block", "mlz_encode_batch",
     "mlz_decode_batch", "mlz_encode_batch_device", "mlz_decode_batch_device", "mlz_set_option", "mlz_get_timers",
     "mlz_timer_name", "mlz_crc", "mlz_crc_batch_device", "mlz_stream_bound", "mlz_stream_encode", "mlz_stream_decoded_len",
-    "mlz_stream_decode",
+    "mlz_stream_decode", "mlz_get_counter",
 ]
 
 
@@ -54,6 +54,7 @@ def lib():
     L.mlz_set_option.argtypes = [vp, i32, i64]; L.mlz_set_option.restype = i32
     L.mlz_get_timers.argtypes = [vp, C.POINTER(C.c_float), i32]; L.mlz_get_timers.restype = i32
     L.mlz_timer_name.argtypes = [i32]; L.mlz_timer_name.restype = C.c_char_p
+    L.mlz_get_counter.argtypes = [vp, i32]; L.mlz_get_counter.restype = i64
     L.mlz_crc.argtypes = [vp, vp, sz]; L.mlz_crc.restype = i64
     L.mlz_crc_batch_device.argtypes = [vp, vp, vp, C.POINTER(BlockDesc), i32, vp]; L.mlz_crc_batch_device.restype = i32
     u32, u64 = C.c_uint32, C.c_uint64

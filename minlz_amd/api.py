@@ -92,6 +92,11 @@ class Context:
         n = _lib.lib().mlz_get_timers(self.handle, arr, 16)
         return {_lib.lib().mlz_timer_name(i).decode(): arr[i] for i in range(n) if arr[i] >= 0}
 
+    def combine_stats(self):
+        """(batches run, requests served) by the combining queue of the single-block host calls."""
+        L = _lib.lib()
+        return int(L.mlz_get_counter(self.handle, 0)), int(L.mlz_get_counter(self.handle, 1))
+
     # ---- device-resident batch calls: pointers are raw device addresses (e.g. tensor.data_ptr()) ----
     def encode_batch_device(self, stream, level, d_src, d_dst, descs, d_out_len):
         arr = (BlockDesc * len(descs))(*descs) if not isinstance(descs, C.Array) else descs

@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <condition_variable>
 #include <cstdio>
 #include <cstring>
 #include <mutex>
@@ -55,9 +56,28 @@ const char* kTimerNames[T_COUNT] = {"enc_far_build", "enc_tiles", "enc_layout", 
 
 }  // namespace
 
+// One single-block host call waiting to be run (see submit_single below).
+struct SingleReq {
+    bool encode, with_header, has_dlen;
+    int level;
+    const uint8_t* src; size_t n;
+    uint8_t* dst; size_t cap;
+    size_t dlen;      // decode_block: exact decoded length
+    int64_t out = 0;  // bytes produced (or a negative per-block error)
+    int rc = 0;       // failure of the whole batch
+    bool done = false;
+    bool same_kind(const SingleReq& o) const { return encode == o.encode && with_header == o.with_header && has_dlen == o.has_dlen && level == o.level; }
+};
+
 struct mlz_ctx {
     int device = 0;
     std::mutex mu;
+    // combining queue of the single-block host calls
+    std::mutex q_mu;
+    std::condition_variable q_cv;
+    std::vector<SingleReq*> q_pending;
+    bool q_leader = false;
+    uint64_t q_batches = 0, q_requests = 0;  // mlz_get_counter
     std::string err;
     std::string dev_name;
     hipStream_t stream = nullptr;  // used by the host-pointer calls
@@ -440,6 +460,45 @@ int host_batch(mlz_ctx* c, bool encode, int level, int n, const uint8_t* const* 
     return 0;
 }
 
+// Single-block calls (mlz_encode / mlz_encode_block / mlz_decode / mlz_decode_block) from concurrent threads are
+// combined into batched launches: the reference's Writer and Reader call their block codec from one goroutine
+// per block (writer.go:501-560, reader.go:830-859), and one 8 MiB block alone cannot fill the device (a tile is a
+// serial chain: one block takes about as long as twelve).  Every caller queues its request; whoever finds no
+// batch in flight becomes the leader, takes every queued request of the same kind (up to kCombineMax) and runs
+// them as ONE host batch while later arrivals queue up behind it; the others sleep until their request is done.
+// No timer, no helper thread: a lone caller runs at once, a busy queue batches itself.
+constexpr size_t kCombineMax = 64;
+void submit_single(mlz_ctx* c, SingleReq& rq) {
+    std::unique_lock<std::mutex> lk(c->q_mu);
+    c->q_pending.push_back(&rq);
+    while (!rq.done) {
+        if (c->q_leader) { c->q_cv.wait(lk); continue; }
+        c->q_leader = true;
+        std::vector<SingleReq*> group;
+        {
+            const SingleReq& head = *c->q_pending.front();
+            std::vector<SingleReq*> rest;
+            for (SingleReq* r : c->q_pending) {
+                if (group.size() < kCombineMax && r->same_kind(head)) group.push_back(r); else rest.push_back(r);
+            }
+            c->q_pending.swap(rest);
+        }
+        lk.unlock();
+        const int n = int(group.size());
+        std::vector<const uint8_t*> src(n); std::vector<size_t> slen(n), cap(n), dlen(n);
+        std::vector<uint8_t*> dst(n); std::vector<int64_t> out(n, 0);
+        for (int i = 0; i < n; i++) { src[i] = group[i]->src; slen[i] = group[i]->n; dst[i] = group[i]->dst; cap[i] = group[i]->cap; dlen[i] = group[i]->dlen; }
+        const SingleReq& k = *group[0];
+        const int r = host_batch(c, k.encode, k.level, n, src.data(), slen.data(), dst.data(), cap.data(), out.data(), k.with_header,
+                                 k.has_dlen ? dlen.data() : nullptr);
+        lk.lock();
+        for (int i = 0; i < n; i++) { group[i]->rc = r; group[i]->out = out[i]; group[i]->done = true; }
+        c->q_batches++; c->q_requests += uint64_t(n);
+        c->q_leader = false;
+        c->q_cv.notify_all();
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -525,18 +584,19 @@ int64_t mlz_encode(mlz_ctx* c, int level, const uint8_t* src, size_t n, uint8_t*
     if (n > kMaxBlockSize) return -MLZ_ERR_TOO_LARGE;
     if (int64_t(dst_cap) < mlz_max_encoded_len(n)) return -MLZ_ERR_DST_TOO_SMALL;
     if (!valid_level(level)) return -MLZ_ERR_INVALID_LEVEL;
-    int64_t out = 0;
-    int r = host_batch(c, true, level, 1, &src, &n, &dst, &dst_cap, &out, true, nullptr);
-    return r ? r : out;
+    SingleReq rq{true, true, false, level, src, n, dst, dst_cap, 0};
+    submit_single(c, rq);
+    return rq.rc ? rq.rc : rq.out;
 }
 
 int64_t mlz_encode_block(mlz_ctx* c, int level, const uint8_t* src, size_t n, uint8_t* dst, size_t dst_cap) {
     if (!c || (!src && n) || !dst) return -MLZ_ERR_ARG;
     if (n > kMaxBlockSize) return -MLZ_ERR_TOO_LARGE;
     if (dst_cap < n) return -MLZ_ERR_DST_TOO_SMALL;
-    int64_t out = 0;
-    int r = host_batch(c, true, level, 1, &src, &n, &dst, &dst_cap, &out, false, nullptr);
-    return r ? r : out;
+    if (!valid_level(level)) return -MLZ_ERR_INVALID_LEVEL;
+    SingleReq rq{true, false, false, level, src, n, dst, dst_cap, 0};
+    submit_single(c, rq);
+    return rq.rc ? rq.rc : rq.out;
 }
 
 int64_t mlz_decode(mlz_ctx* c, const uint8_t* src, size_t n, uint8_t* dst, size_t dst_cap) {
@@ -548,21 +608,19 @@ int64_t mlz_decode(mlz_ctx* c, const uint8_t* src, size_t n, uint8_t* dst, size_
     if (dlen > dst_cap) return -MLZ_ERR_DST_TOO_SMALL;
     (void)dl;
     if (dlen == 0) return 0;
-    int64_t out = 0;
-    uint8_t* dp = dst; size_t cap = dst_cap;
-    int r = host_batch(c, false, 0, 1, &src, &n, &dp, &cap, &out, true, nullptr);
-    return r ? r : out;
+    SingleReq rq{false, true, false, 0, src, n, dst, dst_cap, 0};
+    submit_single(c, rq);
+    return rq.rc ? rq.rc : rq.out;
 }
 
 int mlz_decode_block(mlz_ctx* c, const uint8_t* src, size_t clen, uint8_t* dst, size_t n) {
     if (!c || (!src && clen) || (!dst && n)) return -MLZ_ERR_ARG;
     if (n > kMaxBlockSize) return -MLZ_ERR_TOO_LARGE;
     if (n == 0) return clen == 0 ? 0 : 1;
-    int64_t out = 0;
-    size_t cap = n;
-    int r = host_batch(c, false, 0, 1, &src, &clen, &dst, &cap, &out, false, &n);
-    if (r) return r;
-    return out == int64_t(n) ? 0 : 1;
+    SingleReq rq{false, false, true, 0, src, clen, dst, n, n};
+    submit_single(c, rq);
+    if (rq.rc) return rq.rc;
+    return rq.out == int64_t(n) ? 0 : 1;
 }
 
 int mlz_encode_batch(mlz_ctx* c, int level, int n, const uint8_t* const* src, const size_t* src_len, uint8_t* const* dst, const size_t* dst_cap,
@@ -621,6 +679,12 @@ int mlz_set_option(mlz_ctx* c, int opt, int64_t value) {
     case MLZ_TIMER_ENABLE: c->timing = value != 0; for (bool& u : c->ev_used) u = false; return 0;
     default: return -MLZ_ERR_ARG;
     }
+}
+
+int64_t mlz_get_counter(mlz_ctx* c, int which) {
+    if (!c) return -MLZ_ERR_ARG;
+    std::lock_guard<std::mutex> lk(c->q_mu);
+    return which == 0 ? int64_t(c->q_batches) : which == 1 ? int64_t(c->q_requests) : -MLZ_ERR_ARG;
 }
 
 int mlz_get_timers(mlz_ctx* c, float* ms, int cap) {

@@ -213,3 +213,47 @@ def test_device_batch_unaligned_offsets(ctx):
         assert dhost[do:do + p.size].tobytes() == p.tobytes()
         gmask[do:do + p.size] = False
     assert (dhost[gmask] == 0xA5).all()
+
+
+def test_concurrent_single_block_calls(ctx):
+    # The reference's Writer/Reader call the block codec from one goroutine per block (writer.go:501-560,
+    # reader.go:830-859); the C ABI must be re-entrant.  Concurrent single-block calls are combined
+    # into batched launches: results must equal the one-at-a-time results, errors must stay per call.
+    import threading
+    blocks = [synth.text_like(1 << 20, 40 + i).tobytes() for i in range(6)] + [synth.json_like(700_000).tobytes(), b"", b"tiny",
+              synth.random_bytes(300_000).tobytes(), synth.pattern("zeros", 200_000).tobytes(), synth.text_like(8 << 20, 77).tobytes()]
+    serial_enc = [mz.Encode(b, 1, ctx) for b in blocks]
+    serial_body = [mz.encode_block(b, 2, ctx) for b in blocks]
+    b0, r0 = ctx.combine_stats()
+    res = {}
+    errs = []
+
+    def work(i):
+        try:
+            b = blocks[i % len(blocks)]
+            kind = i % 4
+            if kind == 0:
+                res[i] = mz.Encode(b, 1, ctx) == serial_enc[i % len(blocks)]
+            elif kind == 1:
+                res[i] = mz.Decode(serial_enc[i % len(blocks)], ctx) == b
+            elif kind == 2:
+                res[i] = mz.encode_block(b, 2, ctx) == serial_body[i % len(blocks)]
+            else:
+                body = serial_body[i % len(blocks)]
+                if body:
+                    res[i] = mz.decode_block(body, len(b), ctx) == (0, b)
+                else:  # incompressible: a corrupt body must come back as code 1 for this call only
+                    res[i] = mz.decode_block(b"\xff" * 8, 100, ctx)[0] == 1
+        except Exception as ex:  # noqa: BLE001
+            errs.append((i, repr(ex)))
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(96)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errs, errs[:3]
+    assert len(res) == 96 and all(res.values()), [i for i, ok in res.items() if not ok][:8]
+    b1, r1 = ctx.combine_stats()
+    assert r1 - r0 == 96
+    assert b1 - b0 < 96          # at least some calls shared a launch

@@ -127,8 +127,10 @@ int64_t mlz_stream_decode(mlz_ctx* ctx, uint32_t flags, const uint8_t* src, size
 #define MLZ_OPT_DECODE_ALGO 1  /* 0 = parallel (default), 1 = serial one-wave-per-block */
 #define MLZ_OPT_ENCODE_FAR 2   /* 0 = tile-local matches only, 1 = + far matches (default) */
 int mlz_set_option(mlz_ctx* ctx, int opt, int64_t value);
-/* Milliseconds spent in each kernel family during the last *_batch_device call, measured with
- * HIP events on the caller's stream (only recorded when timing was enabled). */
+/* Milliseconds spent in each kernel family, measured with HIP events on the caller's stream.
+ * mlz_set_option(ctx, MLZ_TIMER_ENABLE, 1): the last *_batch_device call (mlz_get_timers waits for it);
+ * (ctx, MLZ_TIMER_ENABLE, 2): running mean over all calls since then — events are read back several calls
+ * late, so nothing waits on the device per call; 0 = off. */
 #define MLZ_TIMER_ENABLE 100
 int mlz_get_timers(mlz_ctx* ctx, float* ms, int cap); /* returns number of timers written */
 const char* mlz_timer_name(int idx);

@@ -106,12 +106,24 @@ struct mlz_ctx {
     int decode_algo = 0;
     int encode_far = 1;
     int encode_staged = 0;
-    bool timing = false;
+    int timing = 0;  // 0 off, 1 = the last call's kernel times, 2 = running mean over the calls since it was enabled (no sync per call)
     int debug_status = 0;
     bool prof_on = false;
     DevBuf d_prof;
     hipEvent_t ev[T_COUNT][2] = {};
     bool ev_used[T_COUNT] = {};
+    // timing == 2: a ring of event pairs per timer, resolved kTimerRing uses later (long complete by then), so
+    // reading the clock never stalls the caller and launches can run ahead of the device
+    static constexpr int kTimerRing = 8;
+    hipEvent_t evr[T_COUNT][kTimerRing][2] = {};
+    uint64_t ev_cnt[T_COUNT] = {}, ev_res[T_COUNT] = {};
+    double acc_ms[T_COUNT] = {};
+    void resolve_one(int id) {
+        const int slot = int(ev_res[id] % kTimerRing);
+        float t = 0;
+        if (hipEventSynchronize(evr[id][slot][1]) == hipSuccess && hipEventElapsedTime(&t, evr[id][slot][0], evr[id][slot][1]) == hipSuccess) acc_ms[id] += t;
+        ev_res[id]++;
+    }
 };
 
 namespace {
@@ -128,10 +140,15 @@ namespace {
 struct Timer {
     mlz_ctx* c; int id; hipStream_t s;
     Timer(mlz_ctx* c_, int id_, hipStream_t s_) : c(c_), id(id_), s(s_) {
-        if (c->timing) { (void)hipEventRecord(c->ev[id][0], s); }
+        if (c->timing == 1) { (void)hipEventRecord(c->ev[id][0], s); }
+        else if (c->timing == 2) {
+            while (c->ev_cnt[id] - c->ev_res[id] >= uint64_t(mlz_ctx::kTimerRing)) c->resolve_one(id);
+            (void)hipEventRecord(c->evr[id][c->ev_cnt[id] % mlz_ctx::kTimerRing][0], s);
+        }
     }
     ~Timer() {
-        if (c->timing) { (void)hipEventRecord(c->ev[id][1], s); c->ev_used[id] = true; }
+        if (c->timing == 1) { (void)hipEventRecord(c->ev[id][1], s); c->ev_used[id] = true; }
+        else if (c->timing == 2) { (void)hipEventRecord(c->evr[id][c->ev_cnt[id] % mlz_ctx::kTimerRing][1], s); c->ev_cnt[id]++; }
     }
 };
 
@@ -542,6 +559,10 @@ void mlz_destroy(mlz_ctx* c) {
     if (c->s_out) (void)hipStreamDestroy(c->s_out);
     for (hipEvent_t e : c->evpool) (void)hipEventDestroy(e);
     for (int i = 0; i < T_COUNT; i++)
+        for (int k = 0; k < mlz_ctx::kTimerRing; k++)
+            for (int e = 0; e < 2; e++)
+                if (c->evr[i][k][e]) (void)hipEventDestroy(c->evr[i][k][e]);
+    for (int i = 0; i < T_COUNT; i++)
         for (int k = 0; k < 2; k++)
             if (c->ev[i][k]) (void)hipEventDestroy(c->ev[i][k]);
     if (c->upload_done) (void)hipEventDestroy(c->upload_done);
@@ -676,7 +697,17 @@ int mlz_set_option(mlz_ctx* c, int opt, int64_t value) {
         if (hipMemcpy(reinterpret_cast<void*>(value), c->d_prof.as<uint8_t>() + 256, kProfBytes - 256, hipMemcpyDeviceToHost) != hipSuccess) return -MLZ_ERR_HIP;
         return 0;
     }
-    case MLZ_TIMER_ENABLE: c->timing = value != 0; for (bool& u : c->ev_used) u = false; return 0;
+    case MLZ_TIMER_ENABLE:
+        if (value < 0 || value > 2) return -MLZ_ERR_ARG;
+        if (value == 2) {
+            for (int i = 0; i < T_COUNT; i++)
+                for (int k = 0; k < mlz_ctx::kTimerRing; k++)
+                    for (int e = 0; e < 2; e++)
+                        if (!c->evr[i][k][e]) HIPCHK(c, hipEventCreate(&c->evr[i][k][e]));
+        }
+        c->timing = int(value);
+        for (int i = 0; i < T_COUNT; i++) { c->ev_used[i] = false; c->ev_cnt[i] = c->ev_res[i] = 0; c->acc_ms[i] = 0; }
+        return 0;
     default: return -MLZ_ERR_ARG;
     }
 }
@@ -693,6 +724,11 @@ int mlz_get_timers(mlz_ctx* c, float* ms, int cap) {
     int n = std::min<int>(cap, T_COUNT);
     for (int i = 0; i < n; i++) {
         ms[i] = -1.f;
+        if (c->timing == 2) {
+            while (c->ev_res[i] < c->ev_cnt[i]) c->resolve_one(i);
+            if (c->ev_res[i]) ms[i] = float(c->acc_ms[i] / double(c->ev_res[i]));
+            continue;
+        }
         if (c->ev_used[i]) {
             if (hipEventSynchronize(c->ev[i][1]) != hipSuccess) continue;
             float t = 0;

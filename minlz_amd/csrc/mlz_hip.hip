@@ -389,9 +389,15 @@ int decode_parallel(mlz_ctx* c, hipStream_t st, const uint8_t* d_src, uint8_t* d
         else if (tiles)
             hipLaunchKernelGGL(dec_exec2_kernel, dim3(tiles), dim3(kExecThreads), kExecLds, st, d_src, d_dst, blocks, tile_block, dec, tile_start, tok_mask,
                                chunk_d, chunk_rep, order, tile_done, ticket, tiles, prof);
-        if (jump && segs)  // returns at once unless D3c flagged a general block
-            hipLaunchKernelGGL(dec_general_kernel, dim3(c->n_cus), dim3(kGenThreads), 0, st, d_src, d_dst, blocks, seg_block, tile_block, dec, tok_mask,
-                               chunk_d, chunk_rep, c->d_idx.as<uint32_t>(), gen, segs, tiles);
+        if (jump && segs) {  // returns at once unless D3c flagged a general block
+            static bool gen_attr = false;
+            if (!gen_attr) {
+                HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(dec_general_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kGenLds));
+                gen_attr = true;
+            }
+            hipLaunchKernelGGL(dec_general_kernel, dim3(c->n_cus), dim3(kGenThreads), kGenLds, st, d_src, d_dst, blocks, seg_block, tile_block, dec, tok_mask,
+                               chunk_d, chunk_rep, tile_start, c->d_idx.as<uint32_t>(), gen, segs, tiles);
+        }
         hipLaunchKernelGGL(dec_finish_kernel, dim3((n + 63) / 64), dim3(64), 0, st, dec, d_out_len, n, c->debug_status);
     }
     HIPCHK(c, hipGetLastError());

@@ -345,7 +345,7 @@ int decode_parallel(mlz_ctx* c, hipStream_t st, const uint8_t* d_src, uint8_t* d
     // byte of workspace is affordable (<= 4 GiB) and the current exec pass is in use.
     const size_t idx_bytes = (size_t(tiles) << kTileLog) * 4;
     const bool jump = c->general_algo == 0 && c->decode_algo == 0 && tiles > 0 && idx_bytes <= (size_t(4) << 30);
-    if (jump) HIPCHK(c, c->d_idx.ensure(idx_bytes));
+    if (jump) HIPCHK(c, c->d_idx.ensure(idx_bytes + size_t(tiles) * 128));  // + phase J's "all literal" flags, 128 per tile
     const BlockInfo* blocks = c->d_blocks.as<BlockInfo>();
     const uint32_t* tile_block = c->d_tile_block.as<uint32_t>();
     const uint32_t* seg_block = c->d_seg_block.as<uint32_t>();
@@ -396,7 +396,7 @@ int decode_parallel(mlz_ctx* c, hipStream_t st, const uint8_t* d_src, uint8_t* d
                 gen_attr = true;
             }
             hipLaunchKernelGGL(dec_general_kernel, dim3(c->n_cus), dim3(kGenThreads), kGenLds, st, d_src, d_dst, blocks, seg_block, tile_block, dec, tok_mask,
-                               chunk_d, chunk_rep, tile_start, c->d_idx.as<uint32_t>(), gen, segs, tiles);
+                               chunk_d, chunk_rep, tile_start, c->d_idx.as<uint32_t>(), c->d_idx.as<uint8_t>() + idx_bytes, gen, segs, tiles);
         }
         hipLaunchKernelGGL(dec_finish_kernel, dim3((n + 63) / 64), dim3(64), 0, st, dec, d_out_len, n, c->debug_status);
     }

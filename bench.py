@@ -180,7 +180,7 @@ def main():
                     "algorithmic_bytes_per_launch": alg, "avg_launch_ms": round(kavg[dom], 4)}
 
     cpu = None
-    if not args.no_cpu:
+    if not args.no_cpu and world == 1:   # the CPU leg runs on rank 0 of the single-GPU run only
         import oracle as O
         threads = os.cpu_count() or 1
         sample = host[:min(S, 8 * BLOCK)]

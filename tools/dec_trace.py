@@ -32,6 +32,8 @@ ntiles = sum((l + (32 << 10) - 1) // (32 << 10) for l in blk_len)
 t = t[:ntiles]
 lvl = (t[:, 3] >> np.uint64(60)).astype(int)
 tt = t.copy(); tt[:, 3] &= np.uint64((1 << 60) - 1)
+hwid = (tt[:, 0] >> np.uint64(40)).astype(np.int64); tt[:, 0] &= np.uint64((1 << 40) - 1)
+nchunks = (tt[:, 1] >> np.uint64(48)).astype(int); tt[:, 1] &= np.uint64((1 << 48) - 1)
 t0 = tt[:, 0].min()
 us = (tt - t0).astype(np.float64) / 100.0  # 100 MHz -> microseconds
 print("tiles", ntiles, "span %.0f us" % us[:, 3].max())
@@ -42,3 +44,24 @@ for L in range(4):
     print("level %d n=%d  start %.0f..%.0f  ready %.0f..%.0f (median %.0f)  loopend median %.0f  end %.0f..%.0f | wait med %.0f  loop med %.0f p90 %.0f max %.0f  flush med %.0f" % (
         L, m.sum(), u[:, 0].min(), u[:, 0].max(), u[:, 1].min(), u[:, 1].max(), np.median(u[:, 1]), np.median(u[:, 2]), u[:, 3].min(), u[:, 3].max(),
         np.median(u[:, 1] - u[:, 0]), np.median(u[:, 2] - u[:, 1]), np.percentile(u[:, 2] - u[:, 1], 90), (u[:, 2] - u[:, 1]).max(), np.median(u[:, 3] - u[:, 2])))
+
+for L in range(4):
+    m = lvl == L
+    loop = us[m, 2] - us[m, 1]
+    nc = nchunks[m]
+    r = np.corrcoef(loop, nc)[0, 1]
+    fit = np.polyfit(nc, loop, 1)
+    print("level %d: chunks per tile %d..%d (median %d); corr(loop time, chunks) = %.2f; loop = %.2f us/chunk * chunks + %.0f us; residual std %.1f us" % (
+        L, nc.min(), nc.max(), np.median(nc), r, fit[0], fit[1], np.std(loop - np.polyval(fit, nc))))
+
+# placement: tiles of level 0 per CU and how their loop time depends on it
+xcc = hwid & 0xf; hw = hwid >> 4
+cu = (hw >> 8) & 0xf; sh = (hw >> 12) & 1; se = (hw >> 13) & 7
+cuid = xcc * 1000 + se * 100 + sh * 50 + cu
+m0 = lvl == 0
+ids, inv, cnt = np.unique(cuid[m0], return_inverse=True, return_counts=True)
+print("distinct CUs seen by level-0 tiles:", ids.size, " tiles per CU histogram:", np.bincount(cnt))
+loop0 = (us[m0, 2] - us[m0, 1])
+for k in sorted(set(cnt)):
+    sel = cnt[inv] == k
+    print("  level-0 tiles on CUs holding %d of them: n=%d loop median %.0f max %.0f" % (k, sel.sum(), np.median(loop0[sel]), loop0[sel].max()))

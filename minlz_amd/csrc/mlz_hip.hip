@@ -245,7 +245,7 @@ int encode_device_locked(mlz_ctx* c, hipStream_t st, int level, const uint8_t* d
                 far_attr = true;
             }
             hipLaunchKernelGGL(far_build_kernel, dim3(kFarSlices, epochs, n), dim3(1024), 4u << kFarSliceBits, st, d_src, blocks,
-                               c->d_far.as<uint32_t>(), epochs);
+                               c->d_far.as<uint32_t>(), epochs, level_pattern_of(level == MLZ_LEVEL_BALANCED ? 2 : 1));
         }
         {
             Timer t(c, T_ENC_TILES, st);

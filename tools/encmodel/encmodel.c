@@ -72,11 +72,15 @@ static size_t mlen(const uint8_t* a, const uint8_t* b, size_t max) {
     return n;
 }
 
-static const int LPAT[4][8] = {{0,1,2,3,0,1,2,3},{0,2,1,2,0,2,1,2},{0,1,0,1,0,1,0,1},{0,1,2,3,4,5,6,7}};
+static const int LPAT[16][16] = {
+ {0,1,2,3,0,1,2,3,0,1,2,3,0,1,2,3},{0,2,1,2,0,2,1,2,0,2,1,2,0,2,1,2},{0,1,0,1,0,1,0,1,0,1,0,1,0,1,0,1},{0,1,2,3,4,5,6,7,0,1,2,3,4,5,6,7},
+ {0,1,2,3,1,2,3,2,0,1,2,3,1,2,3,2},{0,1,2,3,1,2,3,3,0,1,2,3,1,2,3,3},{0,1,2,3,2,1,2,3,0,1,2,3,2,1,2,3},{0,1,2,1,2,3,2,3,0,1,2,1,2,3,2,3},
+ {0,1,2,3,1,2,3,2,1,2,3,2,1,2,3,3},{0,1,2,3,1,2,3,1,2,3,1,2,3,1,2,3},{0,1,2,3,2,3,1,2,3,2,3,1,2,3,2,3},{0,1,2,3,3,1,2,3,3,1,2,3,3,1,2,3},
+ {0,1,2,2,3,3,1,2,2,3,3,1,2,2,3,3},{0,1,1,2,2,3,3,1,1,2,2,3,3,2,3,3},{0,1,2,3,1,2,3,2,3,1,2,3,2,3,2,3},{0,1,2,3,1,2,3,1,2,3,2,3,1,2,3,3}};
 static inline int tile_level(size_t t, const void* Pv);
 typedef struct { size_t out; size_t n_near, n_rep, n_far, far_bytes, near_bytes, lit_bytes; size_t depth_hist[16]; } stats;
 
-static inline int tile_level(size_t t, const void* Pv) { const params* P = (const params*)Pv; if (!P->nlevels) return 0; return LPAT[P->lpat][t & 7]; }
+static inline int tile_level(size_t t, const void* Pv) { const params* P = (const params*)Pv; if (!P->nlevels) return 0; return LPAT[P->lpat][t & 15]; }
 /* encode one block of n bytes; returns token-stream size (no header) */
 size_t model_block(const uint8_t* src, size_t n, const params* P, stats* st) {
     size_t T = (size_t)1 << P->tile_log;

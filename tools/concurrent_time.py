@@ -11,7 +11,7 @@ N = 8 << 20
 data = synth.text_like(16 * N, 1)
 blocks = [data[i * N:(i + 1) * N] for i in range(16)]
 encs = [mz.Encode(b, 1, ctx) for b in blocks]
-for T in (1, 4, 16):
+for T in (1, 2, 4, 8, 16):
     for what in ("encode", "decode"):
         reps = 4
         L = _lib.lib()

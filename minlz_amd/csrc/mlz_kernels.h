@@ -15,7 +15,7 @@ namespace mlz {
 #define MLZ_TILE_LOG 15
 #endif
 constexpr int kTileLog = MLZ_TILE_LOG;
-constexpr uint32_t kTile = 1u << kTileLog;           // 64 KiB of uncompressed data
+constexpr uint32_t kTile = 1u << kTileLog;           // 32 KiB of uncompressed data
 constexpr uint32_t kTileScratch = kTile + kTile / 16 + 2048;  // worst-case tokens per tile + flush slack (multiple of 16)
 
 struct BlockInfo {

@@ -136,7 +136,9 @@ int mlz_get_timers(mlz_ctx* ctx, float* ms, int cap); /* returns number of timer
 const char* mlz_timer_name(int idx);
 /* Counters of the combining queue behind the single-block host calls (mlz_encode, mlz_encode_block, mlz_decode,
  * mlz_decode_block): concurrent callers — one goroutine per block in the reference's Writer/Reader, writer.go:501-560,
- * reader.go:830-859 — are run as one batched launch.  which: 0 = batches run, 1 = requests served. */
+ * reader.go:830-859 — are run as one batched launch.  which: 0 = batches run, 1 = requests served.
+ * which = 2: blocks of the last decode call that matched neither tile-level pattern of this library's encoder and went
+ * through the position-independent (pointer-jumping) path — 0 for streams made by this library. */
 int64_t mlz_get_counter(mlz_ctx* ctx, int which);
 
 #ifdef __cplusplus

@@ -97,6 +97,10 @@ class Context:
         L = _lib.lib()
         return int(L.mlz_get_counter(self.handle, 0)), int(L.mlz_get_counter(self.handle, 1))
 
+    def general_blocks(self):
+        """Blocks of the last decode call that took the path for streams of other encoders (mlz_get_counter 2)."""
+        return int(_lib.lib().mlz_get_counter(self.handle, 2))
+
     # ---- device-resident batch calls: pointers are raw device addresses (e.g. tensor.data_ptr()) ----
     def encode_batch_device(self, stream, level, d_src, d_dst, descs, d_out_len):
         arr = (BlockDesc * len(descs))(*descs) if not isinstance(descs, C.Array) else descs

@@ -78,6 +78,7 @@ struct mlz_ctx {
     std::vector<SingleReq*> q_pending;
     bool q_leader = false;
     uint64_t q_batches = 0, q_requests = 0;  // mlz_get_counter
+    void* last_gen = nullptr;                // GenCtl of the last decode call (device memory)
     std::string err;
     std::string dev_name;
     hipStream_t stream = nullptr;  // used by the host-pointer calls
@@ -341,6 +342,7 @@ int decode_parallel(mlz_ctx* c, hipStream_t st, const uint8_t* d_src, uint8_t* d
     uint32_t* tile_done = reinterpret_cast<uint32_t*>(ws + o_done);
     uint32_t* ticket = reinterpret_cast<uint32_t*>(ws + o_ticket);
     GenCtl* gen = reinterpret_cast<GenCtl*>(ws + o_gen);
+    c->last_gen = gen;
     // General blocks (streams of other encoders) go through the pointer-jumping pass when its 4 B per output
     // byte of workspace is affordable (<= 4 GiB) and the current exec pass is in use.
     const size_t idx_bytes = (size_t(tiles) << kTileLog) * 4;
@@ -720,6 +722,14 @@ int mlz_set_option(mlz_ctx* c, int opt, int64_t value) {
 
 int64_t mlz_get_counter(mlz_ctx* c, int which) {
     if (!c) return -MLZ_ERR_ARG;
+    if (which == 2) {  // blocks of the last decode call that fit neither level pattern (waits for the device)
+        std::lock_guard<std::mutex> lk(c->mu);
+        if (!c->last_gen) return 0;
+        uint32_t v = 0;
+        if (hipSetDevice(c->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess ||
+            hipMemcpy(&v, c->last_gen, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) return -MLZ_ERR_HIP;
+        return int64_t(v);
+    }
     std::lock_guard<std::mutex> lk(c->q_mu);
     return which == 0 ? int64_t(c->q_batches) : which == 1 ? int64_t(c->q_requests) : -MLZ_ERR_ARG;
 }

@@ -224,3 +224,20 @@ def test_general_block_paths_agree(ctx):
         except O.OracleError:
             o = ("err", "ErrCorrupt")
         assert (v[0] == o[0]) and (v[0] == "err" or v[1] == o[1])
+
+
+def test_own_streams_take_the_tile_path(ctx):
+    # Streams of this library's encoder must be recognised as level-conformant at every level (fast pattern at level 1,
+    # dense pattern at level 2); only blocks of other encoders with cross-tile copies go through the
+    # pointer-jumping path.  Guards against a silent 3x decode slow-down if encoder and decoder ever disagree.
+    d = synth.text_like(3 << 20, 9)
+    for level in (-1, 1, 2):
+        e = mz.Encode(d, level, ctx)
+        assert mz.Decode(e, ctx) == d.tobytes()
+        assert ctx.general_blocks() == 0, level
+    e = O.encode(d, 1)   # the reference's algorithm: copies from any earlier byte
+    assert mz.Decode(e, ctx) == d.tobytes()
+    assert ctx.general_blocks() == 1
+    small = [O.encode(d[i << 16:(i + 1) << 16], 2) for i in range(8)]   # two tiles per block: general only when a copy straddles them
+    assert mz.decode_batch(small, ctx) == [d[i << 16:(i + 1) << 16].tobytes() for i in range(8)]
+    assert 0 <= ctx.general_blocks() <= 8

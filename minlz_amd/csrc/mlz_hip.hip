@@ -398,7 +398,7 @@ int decode_parallel(mlz_ctx* c, hipStream_t st, const uint8_t* d_src, uint8_t* d
                 gen_attr = true;
             }
             hipLaunchKernelGGL(dec_general_kernel, dim3(c->n_cus), dim3(kGenThreads), kGenLds, st, d_src, d_dst, blocks, seg_block, tile_block, dec, tok_mask,
-                               chunk_d, chunk_rep, tile_start, c->d_idx.as<uint32_t>(), c->d_idx.as<uint8_t>() + idx_bytes, gen, segs, tiles);
+                               chunk_d, chunk_rep, tile_start, c->d_idx.as<uint32_t>(), c->d_idx.as<uint8_t>() + idx_bytes, gen, segs, tiles, uint32_t(n));
         }
         hipLaunchKernelGGL(dec_finish_kernel, dim3((n + 63) / 64), dim3(64), 0, st, dec, d_out_len, n, c->debug_status);
     }

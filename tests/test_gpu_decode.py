@@ -244,3 +244,35 @@ def test_own_streams_take_the_tile_path(ctx):
         small = [O.encode(d[i << 16:(i + 1) << 16], lv) for i in range(8)]
         assert mz.decode_batch(small, ctx) == [d[i << 16:(i + 1) << 16].tobytes() for i in range(8)]
         assert ctx.general_blocks() == 0, lv
+
+
+def test_many_general_blocks_take_the_tile_ordered_phase(ctx):
+    # 20 or more general blocks in one batch are resolved tile by tile in order (phase S of mlz_decode_general.hip.inc)
+    # instead of by pointer-jumping rounds: same bytes, same verdicts.
+    d = synth.text_like(24 * (256 << 10), 13)
+    blocks = [d[i * (256 << 10):(i + 1) * (256 << 10)].tobytes() for i in range(24)]
+    blocks[5] = synth.json_like(200_001).tobytes()          # ragged size, other statistics
+    blocks[11] = synth.pattern("half", 256 << 10).tobytes()  # long literal run + long copies
+    encs = [O.encode(b, 1 + (i % 3)) for i, b in enumerate(blocks)]
+    assert mz.decode_batch(encs, ctx) == blocks
+    assert ctx.general_blocks() >= 20
+    # a stream that lies about a copy (offset beyond the start) in the middle of such a batch: that block fails, the others do not
+    bad = bytearray(encs[7])
+    body0 = 1 + 3  # header: 00 + uvarint(262144) is 3 bytes
+    bad[body0:body0 + 3] = bytes([(4 - 4) << 2 | 2, 0xff, 0xff])   # copy2, offset 65535+64 at output position 0
+    outs = [np.zeros(len(b), dtype=np.uint8) for b in blocks]
+    import ctypes as C
+    from minlz_amd import _lib
+    n = len(blocks)
+    arrs = [np.frombuffer(bytes(e), dtype=np.uint8) for e in encs]
+    arrs[7] = np.frombuffer(bytes(bad), dtype=np.uint8)
+    vp, sz = C.c_void_p, C.c_size_t
+    srcp = (vp * n)(*[a.ctypes.data for a in arrs]); srcl = (sz * n)(*[a.size for a in arrs])
+    dstp = (vp * n)(*[o.ctypes.data for o in outs]); dstc = (sz * n)(*[o.size for o in outs])
+    ol = (C.c_int64 * n)()
+    assert _lib.lib().mlz_decode_batch(ctx.handle, n, srcp, srcl, dstp, dstc, ol) == 0
+    for i in range(n):
+        if i == 7:
+            assert ol[i] == -1 and O.decode_body(bytes(bad[body0:]), len(blocks[7]))[0] == 1   # ErrCorrupt, like the oracle
+        else:
+            assert ol[i] == len(blocks[i]) and outs[i].tobytes() == blocks[i]

@@ -108,12 +108,13 @@ def main():
     assert torch.equal(dec[:S], src), "GPU decode(encode(x)) != x"
     C_total = sum(clens)
 
+    gathered = [torch.empty_like(enc_len) for _ in range(world)] if dist is not None else None
+
     def step():
         run_encode()
         if dist is not None:
             # the stream writer's only exchange: every rank learns every block's compressed size
             # (output offsets / index, writer.go:223-243) — an RCCL all_gather of nblk int64
-            gathered = [torch.empty_like(enc_len) for _ in range(world)]
             dist.all_gather(gathered, enc_len)
         run_decode()
 

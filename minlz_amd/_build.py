@@ -6,7 +6,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc", "mlz_hip.hip")
 SO = os.path.join(HERE, "libminlz_hip.so")
-DEPS = ["mlz_hip.hip", "mlz_format.h", "mlz_kernels.h", "mlz_encode.hip.inc", "mlz_encode_pipe.hip.inc", "mlz_encode_pc.hip.inc", "mlz_decode.hip.inc", "mlz_decode_exec.hip.inc", "mlz_decode_general.hip.inc", "mlz_decode_serial.hip.inc", "mlz_crc.hip.inc", "mlz_stream.hip.inc"]
+DEPS = ["mlz_hip.hip", "mlz_format.h", "mlz_kernels.h", "mlz_encode.hip.inc", "mlz_encode2.hip.inc", "mlz_decode.hip.inc", "mlz_decode_exec.hip.inc", "mlz_decode_general.hip.inc", "mlz_decode_serial.hip.inc", "mlz_crc.hip.inc", "mlz_stream.hip.inc"]
 
 
 def hipcc():

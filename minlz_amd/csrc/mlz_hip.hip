@@ -18,8 +18,7 @@
 #include "mlz_kernels.h"
 
 #include "mlz_encode.hip.inc"
-#include "mlz_encode_pipe.hip.inc"
-#include "mlz_encode_pc.hip.inc"
+#include "mlz_encode2.hip.inc"
 #include "mlz_decode_serial.hip.inc"
 #include "mlz_decode.hip.inc"
 #include "mlz_decode_exec.hip.inc"
@@ -51,8 +50,8 @@ constexpr size_t kProfBytes = 256 + kProfTiles * 32;
 // Levels served on the device (encode.go:25-43); LevelSmallest (3) stays on the host side of the boundary.
 inline bool valid_level(int level) { return level >= MLZ_LEVEL_SUPERFAST && level <= MLZ_LEVEL_BALANCED; }
 
-enum { T_FAR = 0, T_ENC_TILES, T_ENC_LAYOUT, T_ENC_GATHER, T_DEC_PARSE, T_DEC_CHAIN, T_DEC_INDEX, T_DEC_EXEC, T_DEC_SERIAL, T_CRC, T_COUNT };
-const char* kTimerNames[T_COUNT] = {"enc_far_build", "enc_tiles", "enc_layout", "enc_gather", "dec_parse", "dec_chain", "dec_index", "dec_exec", "dec_serial", "crc"};
+enum { T_FAR = 0, T_ENC_TILES, T_ENC_LAYOUT, T_ENC_GATHER, T_DEC_PARSE, T_DEC_CHAIN, T_DEC_INDEX, T_DEC_EXEC, T_DEC_SERIAL, T_CRC, T_ENC_SER, T_COUNT };
+const char* kTimerNames[T_COUNT] = {"enc_far_build", "enc_tiles", "enc_layout", "enc_gather", "dec_parse", "dec_chain", "dec_index", "dec_exec", "dec_serial", "crc", "enc_serialize"};
 
 }  // namespace
 
@@ -91,7 +90,7 @@ struct mlz_ctx {
     hipEvent_t upload_done = nullptr;
     bool upload_pending = false;
     // encode workspace
-    DevBuf d_scratch, d_tile_size, d_tile_out, d_flags, d_far, d_dummy;
+    DevBuf d_scratch, d_tile_size, d_tile_out, d_flags, d_far, d_recs, d_piece_cnt;
     // decode workspace
     DevBuf d_dec, d_idx;
     int general_algo = 0;  // 0 = pointer-jumping pass for general blocks, 1 = tile chain in the exec pass
@@ -106,7 +105,8 @@ struct mlz_ctx {
     // options
     int decode_algo = 0;
     int encode_far = 1;
-    int encode_staged = 0;
+    int encode_algo = 0;  // 0 = match + serialize kernels (mlz_encode2.hip.inc), 2 = the round-1 wave-per-tile kernel (always used by LevelBalanced)
+    bool enc_attrs = false, far_attr = false, dec_attrs = false, gen_attr = false;  // per device: dynamic-LDS limits raised
     int timing = 0;  // 0 off, 1 = the last call's kernel times, 2 = running mean over the calls since it was enabled (no sync per call)
     int debug_status = 0;
     bool prof_on = false;
@@ -215,84 +215,80 @@ int encode_device_locked(mlz_ctx* c, hipStream_t st, int level, const uint8_t* d
     uint32_t tiles = 0;
     int r = upload_blocks(c, st, desc, n, false, &tiles);
     if (r) return r;
-    HIPCHK(c, c->d_tile_size.ensure(sizeof(uint32_t) * (tiles + 1)));
-    HIPCHK(c, c->d_tile_out.ensure(sizeof(uint32_t) * (tiles + 1)));
+    // LevelFastest / LevelSuperFast: match + serialize kernels on 8 KiB pieces (mlz_encode2.hip.inc);
+    // LevelBalanced (and option 6 = 2): the wave-per-tile kernel of mlz_encode.hip.inc.
+    const bool v2 = level != MLZ_LEVEL_BALANCED && c->encode_algo != 2;
+    const uint32_t sub_log = v2 ? kSubLog : 0;
+    const size_t units = size_t(tiles) << sub_log;
+    HIPCHK(c, c->d_tile_size.ensure(sizeof(uint32_t) * (units + 1)));
+    HIPCHK(c, c->d_tile_out.ensure(sizeof(uint32_t) * (units + 1)));
     HIPCHK(c, c->d_flags.ensure(sizeof(uint32_t) * n));
     const BlockInfo* blocks = c->d_blocks.as<BlockInfo>();
     const uint32_t* tile_block = c->d_tile_block.as<uint32_t>();
     if (level != MLZ_LEVEL_UNCOMPRESSED && tiles > 0) {
-        HIPCHK(c, c->d_scratch.ensure(size_t(tiles) * kTileScratch));
+        HIPCHK(c, c->d_scratch.ensure(v2 ? units * kPieceScratch : size_t(tiles) * kTileScratch));
         uint64_t maxlen = 0;
         for (int i = 0; i < n; i++) maxlen = std::max<uint64_t>(maxlen, std::min<uint64_t>(desc[i].src_len, kMaxBlockSize));
         const uint32_t epochs = uint32_t((maxlen + (1u << kEpochLog) - 1) >> kEpochLog);
-        // LevelBalanced: the same kernel with far matching forced on, both epochs probed and a
-        // cost-aware lazy parse (DESIGN.md "Levels").
+        // LevelBalanced: far matching forced on, both epochs probed and a cost-aware lazy parse (DESIGN.md "Levels").
         // LevelSuperFast: tile-local matches only (no far tables are built or probed).
         const bool far = ((c->encode_far && level != MLZ_LEVEL_SUPERFAST) || level == MLZ_LEVEL_BALANCED) && maxlen > kTile;
-        static bool enc_attrs = false;
-        if (!enc_attrs) {
-            HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(encode_tiles_kernel<true, true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, kEncLdsStaged));
-            HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(encode_tiles_kernel<true, true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, kEncLdsStaged));
-            HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(encode_tiles_kernel<false, true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, kEncLdsStaged));
-            enc_attrs = true;
+        const uint32_t pattern = level_pattern_of(level == MLZ_LEVEL_BALANCED ? 2 : 1);
+        if (!c->enc_attrs) {  // per context = per device
+            HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(match_tiles_kernel<true, MLZ_M2_NW>), hipFuncAttributeMaxDynamicSharedMemorySize, kM2Lds));
+            HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(match_tiles_kernel<false, MLZ_M2_NW>), hipFuncAttributeMaxDynamicSharedMemorySize, kM2Lds));
+            c->enc_attrs = true;
         }
         if (far) {
             Timer t(c, T_FAR, st);
             const size_t words = (size_t(n) * (kLevels - 1) * epochs) << kFarBits;
             HIPCHK(c, c->d_far.ensure(words * 4));
-            static bool far_attr = false;
-            if (!far_attr) {
+            if (!c->far_attr) {
                 HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(far_build_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 4u << kFarSliceBits));
-                far_attr = true;
+                c->far_attr = true;
             }
             hipLaunchKernelGGL(far_build_kernel, dim3(kFarSlices, epochs, n), dim3(1024), 4u << kFarSliceBits, st, d_src, blocks,
-                               c->d_far.as<uint32_t>(), epochs, level_pattern_of(level == MLZ_LEVEL_BALANCED ? 2 : 1));
+                               c->d_far.as<uint32_t>(), epochs, pattern);
         }
-        {
+        const uint32_t* ftab = far ? c->d_far.as<uint32_t>() : nullptr;
+        if (v2) {
+            HIPCHK(c, c->d_recs.ensure(units * kRecPerPiece * sizeof(uint2)));
+            HIPCHK(c, c->d_piece_cnt.ensure(units * sizeof(uint32_t)));
+            {
+                Timer t(c, T_ENC_TILES, st);
+                if (far) hipLaunchKernelGGL((match_tiles_kernel<true, MLZ_M2_NW>), dim3(tiles), dim3(256), kM2Lds, st, d_src, blocks, tile_block,
+                                            c->d_recs.as<uint2>(), c->d_piece_cnt.as<uint32_t>(), ftab, epochs, pattern);
+                else hipLaunchKernelGGL((match_tiles_kernel<false, MLZ_M2_NW>), dim3(tiles), dim3(256), kM2Lds, st, d_src, blocks, tile_block,
+                                        c->d_recs.as<uint2>(), c->d_piece_cnt.as<uint32_t>(), ftab, epochs, pattern);
+            }
+            {
+                Timer t(c, T_ENC_SER, st);
+                hipLaunchKernelGGL(serialize_pieces_kernel, dim3(tiles), dim3(256), kSerLds, st, d_src, blocks, tile_block, c->d_recs.as<uint2>(),
+                                   c->d_piece_cnt.as<uint32_t>(), c->d_scratch.as<uint8_t>(), c->d_tile_size.as<uint32_t>());
+            }
+        } else {
             Timer t(c, T_ENC_TILES, st);
             unsigned long long* prof = c->prof_on ? c->d_prof.as<unsigned long long>() : nullptr;
-            const uint32_t* ftab = far ? c->d_far.as<uint32_t>() : nullptr;
-#define MLZ_LAUNCH_ENC1(F, S, LV, LDS)                                                                                                          \
-    hipLaunchKernelGGL((encode_tiles_kernel<F, S, LV>), dim3(tiles), dim3(64), LDS, st, d_src, blocks, tile_block, c->d_scratch.as<uint8_t>(), \
+#define MLZ_LAUNCH_ENC1(F, LV, LDS)                                                                                                                 \
+    hipLaunchKernelGGL((encode_tiles_kernel<F, false, LV>), dim3(tiles), dim3(64), LDS, st, d_src, blocks, tile_block, c->d_scratch.as<uint8_t>(), \
                        c->d_tile_size.as<uint32_t>(), ftab, epochs, prof)
-#define MLZ_LAUNCH_ENC(F, S, LDS) do { if (F && level == MLZ_LEVEL_BALANCED) MLZ_LAUNCH_ENC1(F, S, 2, (S ? LDS : kEncLdsTwoWay)); else MLZ_LAUNCH_ENC1(F, S, 1, LDS); } while (0)
-            if (c->encode_staged == 1) { if (far) MLZ_LAUNCH_ENC(true, true, kEncLdsStaged); else MLZ_LAUNCH_ENC(false, true, kEncLdsStaged); }
-            else if (c->encode_staged == 4) {  // experiment: producer/consumer pair of waves per tile (mlz_encode_pc.hip.inc)
-                if (!c->d_dummy.p) {
-                    HIPCHK(c, c->d_dummy.ensure(256));
-                    HIPCHK(c, hipMemsetAsync(c->d_dummy.p, 0, 256, st));
-                }
-                const uint8_t* dummy = c->d_dummy.as<uint8_t>();
-                if (far) hipLaunchKernelGGL((encode_tiles_pc_kernel<true>), dim3(tiles), dim3(128), kEncLdsPc, st, d_src, blocks, tile_block,
-                                            c->d_scratch.as<uint8_t>(), c->d_tile_size.as<uint32_t>(), ftab, epochs, dummy, prof);
-                else hipLaunchKernelGGL((encode_tiles_pc_kernel<false>), dim3(tiles), dim3(128), kEncLdsPc, st, d_src, blocks, tile_block,
-                                        c->d_scratch.as<uint8_t>(), c->d_tile_size.as<uint32_t>(), ftab, epochs, dummy, prof);
-            }
-            else if (c->encode_staged != 3) { if (far) MLZ_LAUNCH_ENC(true, false, kEncLdsInPlace); else MLZ_LAUNCH_ENC(false, false, kEncLdsInPlace); }
-            else {  // experiment: software-pipelined kernel (mlz_encode_pipe.hip.inc); same speed, see DESIGN.md section 6
-                if (!c->d_dummy.p) {
-                    HIPCHK(c, c->d_dummy.ensure(256));
-                    HIPCHK(c, hipMemsetAsync(c->d_dummy.p, 0, 256, st));
-                }
-                const uint8_t* dummy = c->d_dummy.as<uint8_t>();
-                if (far) hipLaunchKernelGGL((encode_tiles_pipe_kernel<true>), dim3(tiles), dim3(64), kEncLdsInPlace, st, d_src, blocks, tile_block,
-                                            c->d_scratch.as<uint8_t>(), c->d_tile_size.as<uint32_t>(), ftab, epochs, dummy, prof);
-                else hipLaunchKernelGGL((encode_tiles_pipe_kernel<false>), dim3(tiles), dim3(64), kEncLdsInPlace, st, d_src, blocks, tile_block,
-                                        c->d_scratch.as<uint8_t>(), c->d_tile_size.as<uint32_t>(), ftab, epochs, dummy, prof);
-            }
-#undef MLZ_LAUNCH_ENC
+            if (far && level == MLZ_LEVEL_BALANCED) MLZ_LAUNCH_ENC1(true, 2, kEncLdsTwoWay);
+            else if (far) MLZ_LAUNCH_ENC1(true, 1, kEncLdsInPlace);
+            else MLZ_LAUNCH_ENC1(false, 1, kEncLdsInPlace);
 #undef MLZ_LAUNCH_ENC1
         }
     }
     {
         Timer t(c, T_ENC_LAYOUT, st);
         hipLaunchKernelGGL(encode_layout_kernel, dim3(n), dim3(64), 0, st, blocks, c->d_tile_size.as<uint32_t>(), c->d_tile_out.as<uint32_t>(), d_dst,
-                           d_out_len, c->d_flags.as<uint32_t>(), level, with_header ? 1 : 0);
+                           d_out_len, c->d_flags.as<uint32_t>(), level, with_header ? 1 : 0, sub_log);
     }
     if (tiles > 0) {
         Timer t(c, T_ENC_GATHER, st);
-        hipLaunchKernelGGL(encode_gather_kernel, dim3(tiles), dim3(256), 0, st, d_src, blocks, tile_block, c->d_scratch.as<uint8_t>(),
-                           c->d_tile_size.as<uint32_t>(), c->d_tile_out.as<uint32_t>(), d_dst, c->d_flags.as<uint32_t>(), with_header ? 1 : 0);
+        if (v2) hipLaunchKernelGGL(encode_gather2_kernel, dim3(tiles), dim3(256), 0, st, d_src, blocks, tile_block, c->d_scratch.as<uint8_t>(),
+                                   c->d_tile_size.as<uint32_t>(), c->d_tile_out.as<uint32_t>(), d_dst, c->d_flags.as<uint32_t>(), with_header ? 1 : 0);
+        else hipLaunchKernelGGL(encode_gather_kernel, dim3(tiles), dim3(256), 0, st, d_src, blocks, tile_block, c->d_scratch.as<uint8_t>(),
+                                c->d_tile_size.as<uint32_t>(), c->d_tile_out.as<uint32_t>(), d_dst, c->d_flags.as<uint32_t>(), with_header ? 1 : 0);
     }
     HIPCHK(c, hipGetLastError());
     return 0;
@@ -351,14 +347,13 @@ int decode_parallel(mlz_ctx* c, hipStream_t st, const uint8_t* d_src, uint8_t* d
     const BlockInfo* blocks = c->d_blocks.as<BlockInfo>();
     const uint32_t* tile_block = c->d_tile_block.as<uint32_t>();
     const uint32_t* seg_block = c->d_seg_block.as<uint32_t>();
-    static bool attrs = false;
-    if (!attrs) {
+    if (!c->dec_attrs) {
         HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(dec_exit_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kExitLds));
         HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(dec_index_a_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kIndexLds));
         HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(dec_index_c_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kIndexLds));
         HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(dec_exec_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kTile));
         HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(dec_exec2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kExecLds));
-        attrs = true;
+        c->dec_attrs = true;
     }
     {
         Timer t(c, T_DEC_PARSE, st);
@@ -392,10 +387,9 @@ int decode_parallel(mlz_ctx* c, hipStream_t st, const uint8_t* d_src, uint8_t* d
             hipLaunchKernelGGL(dec_exec2_kernel, dim3(tiles), dim3(kExecThreads), kExecLds, st, d_src, d_dst, blocks, tile_block, dec, tile_start, tok_mask,
                                chunk_d, chunk_rep, order, tile_done, ticket, tiles, prof);
         if (jump && segs) {  // returns at once unless D3c flagged a general block
-            static bool gen_attr = false;
-            if (!gen_attr) {
+            if (!c->gen_attr) {
                 HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(dec_general_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kGenLds));
-                gen_attr = true;
+                c->gen_attr = true;
             }
             hipLaunchKernelGGL(dec_general_kernel, dim3(c->n_cus), dim3(kGenThreads), kGenLds, st, d_src, d_dst, blocks, seg_block, tile_block, dec, tok_mask,
                                chunk_d, chunk_rep, tile_start, c->d_idx.as<uint32_t>(), c->d_idx.as<uint8_t>() + idx_bytes, gen, segs, tiles, uint32_t(n));
@@ -559,7 +553,7 @@ void mlz_destroy(mlz_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
-    for (DevBuf* b : {&c->d_crc, &c->d_prof, &c->d_blocks, &c->d_tile_block, &c->d_seg_block, &c->d_scratch, &c->d_tile_size, &c->d_tile_out, &c->d_flags, &c->d_far, &c->d_dummy, &c->d_dec, &c->d_idx, &c->d_in, &c->d_out, &c->d_len})
+    for (DevBuf* b : {&c->d_crc, &c->d_prof, &c->d_blocks, &c->d_tile_block, &c->d_seg_block, &c->d_scratch, &c->d_tile_size, &c->d_tile_out, &c->d_flags, &c->d_far, &c->d_recs, &c->d_piece_cnt, &c->d_dec, &c->d_idx, &c->d_in, &c->d_out, &c->d_len})
         b->release();
     if (c->pinned) (void)hipHostFree(c->pinned);
     if (c->pinned2) (void)hipHostFree(c->pinned2);
@@ -686,7 +680,7 @@ int mlz_set_option(mlz_ctx* c, int opt, int64_t value) {
     case MLZ_OPT_DECODE_ALGO: c->decode_algo = int(value); return 0;
     case MLZ_OPT_ENCODE_FAR: c->encode_far = int(value); return 0;
     case 8: c->general_algo = int(value); return 0;  // 0 = pointer-jumping pass for general blocks (default), 1 = tile chain
-    case 6: c->encode_staged = int(value); return 0;  // tuning: 0 = in-place tile bytes (default), 1 = LDS-staged tile bytes, 3 = software-pipelined variant
+    case 6: c->encode_algo = int(value); return 0;  // 0 = match + serialize kernels (default), 2 = the round-1 wave-per-tile kernel at LevelFastest / LevelSuperFast
     case 3: c->debug_status = int(value); return 0;  // debug: report failure sites in the error code
     case 4: {  // debug: per-phase cycle counters (16 x u64: 0-7 encode, 8-15 decode)
         c->prof_on = value != 0;

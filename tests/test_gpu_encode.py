@@ -96,8 +96,9 @@ def test_ratio_half_noise(ctx):
 
 def test_huge_zeros(ctx):
     # TestEncodeHuge, encode_test.go:26-50
+    # (the reference only asserts len <= MaxEncodedLen; here: 1024 independent 8 KiB pieces of <= 6 bytes each)
     enc = roundtrip(np.zeros(8 << 20, dtype=np.uint8), ctx)
-    assert len(enc) < 4096
+    assert len(enc) < 8192
 
 
 @pytest.mark.parametrize("kind", ["text", "json"])

@@ -1,0 +1,256 @@
+// encmodel2.cpp — sequential CPU statement of the round-2 tile encoder (match kernel + serialize kernel).
+//
+// NOT the oracle and NOT part of the product: a design tool (ratio of a parameter set without a GPU) and a
+// debugging aid (the HIP kernels' token records can be compared with these one for one).  It models OUR OWN
+// algorithm: 32 KiB tiles staged in LDS, `sub` independent pieces per tile (one wavefront each, near table
+// pre-seeded with the tile's earlier positions), fixed 64-position windows (look-ups before inserts), a greedy
+// walk over the candidate mask, token records {match start, length, offset}, and a second pass that extends
+// matches backwards, chooses the token forms and writes the bytes (the emitters are the product's mlz_format.h).
+//
+// build: g++ -O2 -shared -fPIC -o libencmodel2.so encmodel2.cpp -I../../minlz_amd/csrc
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <vector>
+
+#include "mlz_format.h"
+
+using namespace mlz;
+
+namespace {
+constexpr uint32_t kTileLog = 15, kTile = 1u << kTileLog;
+constexpr int kFarBits = 18, kEpochLog = 21, kFarTagBits = 9, kFarStride = 4, kLevels = 4;
+constexpr uint32_t kFarTagMask = (1u << kFarTagBits) - 1;
+constexpr uint32_t kPatternFast = 0xE4E4E4E4u, kPatternDense = 0xEEE7B9E4u;
+inline int tile_level_p(uint32_t t, uint32_t pat) { return int((pat >> (2 * (t & 15))) & 3); }
+
+inline uint64_t ld64z(const uint8_t* s, size_t p, size_t n) {  // bytes past n read as zero (the LDS pad)
+    uint64_t v = 0;
+    if (p + 8 <= n) memcpy(&v, s + p, 8);
+    else if (p < n) memcpy(&v, s + p, n - p);
+    return v;
+}
+inline uint32_t hash4(uint64_t v, int bits) { return (uint32_t(v) * 2654435761u) >> (32 - bits); }
+struct FarHash { uint32_t idx, tag; };
+inline FarHash far_hash(uint64_t v, int bits) {
+    const uint32_t h = (uint32_t(v) * 0x9E3779B1u) ^ (uint32_t(v >> 32) * 0x85EBCA77u);
+    const uint32_t g = h * 0xC2B2AE3Du;
+    return {g >> (32 - bits), (g >> (32 - bits - kFarTagBits)) & kFarTagMask};
+}
+inline uint32_t common8(uint64_t a, uint64_t b) { const uint64_t d = a ^ b; return d ? uint32_t(__builtin_ctzll(d)) >> 3 : 8; }
+}  // namespace
+
+struct Params {
+    int sub;        // pieces per tile (1, 2, 4, 8)
+    int nw;         // windows per iteration (1 or 2): the repeat offset is the one in force before the iteration
+    int near_bits;  // near table entries (log2)
+    int lazy;       // look-ahead positions (0..3)
+    int use_rep;    // repeat-offset probe (in-tile sources only)
+    int far;        // far tables
+    int lane_cap;   // per-lane extension cap (32)
+    int back;       // backward extension limit in the serialize pass (0..8)
+    int dense;      // level pattern: 0 fast, 1 dense
+    int skip_shift; // growing skip on misses: extra windows = min(7, run >> skip_shift); 0 = off
+    int far_gate;   // 1: far candidate only looked at when the near/repeat winner is shorter than 8
+    int seed;       // 1: pre-seed the near table with the tile's earlier positions
+    int lazy_cost;  // 1: lazy compares length minus token size
+    int min_far;    // minimum far match (8)
+};
+
+struct Rec { uint32_t mp, len, off; };
+
+extern "C" {
+
+// Encodes one block; writes the token stream (no block header) to out (cap >= n + n/8 + 64); returns its size.
+// stats[0] = tokens, [1] = literal bytes, [2] = far tokens, [3] = repeat tokens, [4] = windows probed
+size_t model2_block(const uint8_t* src, size_t n, const Params* P, uint8_t* out, uint64_t* stats) {
+    const uint32_t pat = P->dense ? kPatternDense : kPatternFast;
+    const size_t ntiles = (n + kTile - 1) >> kTileLog;
+    const size_t nepoch = (n + (size_t(1) << kEpochLog) - 1) >> kEpochLog;
+    std::vector<uint32_t> far_tab;
+    if (P->far && n > kTile) {
+        far_tab.assign(size_t(kLevels - 1) * nepoch << kFarBits, 0xffffffffu);
+        for (size_t q = 0; q + 8 <= n; q += kFarStride) {
+            uint64_t v; memcpy(&v, src + q, 8);
+            const FarHash fh = far_hash(v, kFarBits);
+            const int lv = tile_level_p(uint32_t(q >> kTileLog), pat);
+            for (int ls = lv; ls < kLevels - 1; ls++) {
+                uint32_t& e = far_tab[((size_t(ls) * nepoch + (q >> kEpochLog)) << kFarBits) + fh.idx];
+                const uint32_t val = (uint32_t(q) << kFarTagBits) | fh.tag;
+                if (val < e) e = val;
+            }
+        }
+    }
+    const uint32_t piece_len = kTile / uint32_t(P->sub);
+    const int W = 64, NW = P->nw;
+    std::vector<uint16_t> table(size_t(1) << P->near_bits);
+    std::vector<Rec> recs;
+    size_t o = 0;
+    for (size_t t = 0; t < ntiles; t++) {
+        const size_t base = t << kTileLog;
+        const uint32_t tl = uint32_t(n - base < kTile ? n - base : kTile);
+        const uint8_t* s = src + base;
+        const int mylv = tile_level_p(uint32_t(t), pat);
+        const bool far_tile = !far_tab.empty() && mylv > 0;
+        const uint32_t* ftab = far_tile ? &far_tab[(size_t(mylv - 1) * nepoch) << kFarBits] : nullptr;
+        for (uint32_t ps = 0; ps < tl; ps += piece_len) {
+            const uint32_t pe = ps + piece_len < tl ? ps + piece_len : tl;
+            recs.clear();
+            std::fill(table.begin(), table.end(), uint16_t(0));
+            if (P->seed)
+                for (uint32_t p = 0; p < ps; p++) {
+                    const uint32_t h1 = hash4(ld64z(s, p, tl), P->near_bits + 1);
+                    table[h1 >> 1] = uint16_t(p | ((h1 & 1) << 15));
+                }
+            uint32_t cur = ps, pos = ps, rep = 0;
+            while (cur + 4 <= pe) {
+                uint32_t best[128], boff[128];
+                bool valid[128];
+                const int NP = W * NW;
+                for (int w = 0; w < NW; w++) {
+                    uint32_t e[64], hh[64], tg[64];
+                    for (int l = 0; l < W; l++) {
+                        const uint32_t p = cur + w * W + l;
+                        valid[w * W + l] = p + 4 <= pe;
+                        const uint32_t h1 = hash4(ld64z(s, p, tl), P->near_bits + 1);
+                        hh[l] = h1 >> 1; tg[l] = (h1 & 1) << 15;
+                        e[l] = table[hh[l]];
+                    }
+                    for (int l = 0; l < W; l++) if (valid[w * W + l]) table[hh[l]] = uint16_t((cur + w * W + l) | tg[l]);
+                    for (int l = 0; l < W; l++) {
+                        const int i = w * W + l;
+                        const uint32_t p = cur + i;
+                        best[i] = 0; boff[i] = 0;
+                        if (!valid[i]) continue;
+                        if (stats) stats[4]++;
+                        const uint64_t v = ld64z(s, p, tl);
+                        const uint32_t maxl = pe - p;
+                        const uint32_t lim = maxl < uint32_t(P->lane_cap) ? maxl : uint32_t(P->lane_cap);
+                        const uint32_t cand = e[l] & 0x7fffu;
+                        const bool near_ok = cand < p && (e[l] & 0x8000u) == tg[l];
+                        const bool rep_ok = P->use_rep && rep != 0 && rep <= p;
+                        const uint32_t l_near = near_ok ? common8(v, ld64z(s, cand, tl)) : 0;
+                        const uint32_t l_rep = rep_ok ? common8(v, ld64z(s, p - rep, tl)) : 0;
+                        const bool brep = l_rep >= 4;
+                        uint32_t b = brep ? l_rep : 0, bo = brep ? rep : 0;
+                        if (l_near >= 4 && (!brep || l_near > b + 1)) { b = l_near; bo = p - cand; }
+                        if (b == 8 && lim > 8) {
+                            uint32_t k = 8;
+                            while (k < lim && s[p + k] == s[p - bo + k]) k++;   // p + k < pe <= tl
+                            b = k;
+                        }
+                        if (b > maxl) b = maxl;
+                        if (far_tile && !(P->far_gate && b >= 8)) {
+                            const FarHash fh = far_hash(v, kFarBits);
+                            const size_t ep = (base + p) >> kEpochLog;
+                            const uint32_t en = ftab[(ep << kFarBits) + fh.idx];
+                            if ((en & kFarTagMask) == fh.tag) {
+                                const uint32_t fq = en >> kFarTagBits;
+                                const uint32_t off = uint32_t(base) + p - fq;
+                                const uint32_t left = kTile - (fq & (kTile - 1));
+                                if (fq < base && off <= kMaxCopy3Offset && left >= 8) {
+                                    uint64_t fv; memcpy(&fv, src + fq, 8);
+                                    if (fv == v && maxl >= 8) {
+                                        const uint32_t lm = left < lim ? left : lim;
+                                        uint32_t k = 8;
+                                        while (k < lm && s[p + k] == src[fq + k]) k++;
+                                        if (k >= uint32_t(P->min_far) && k > b + 2) { b = k; bo = off; }
+                                    }
+                                }
+                            }
+                        }
+                        if (b < 4) b = 0;
+                        best[i] = b; boff[i] = bo;
+                    }
+                }
+                // lazy
+                bool take[128];
+                for (int i = 0; i < NP; i++) {
+                    take[i] = best[i] >= 4;
+                    if (!take[i]) continue;
+                    auto gain = [&](int j) -> uint32_t {
+                        if (!P->lazy_cost || best[j] < 4) return best[j];
+                        return best[j] - (boff[j] > kMaxCopy2Offset ? 4u : boff[j] > kMaxCopy1Offset ? 3u : 2u);
+                    };
+                    for (int k = 1; k <= P->lazy && i + k < NP; k++)
+                        if (gain(i + k) > gain(i) + uint32_t(k - 1)) { take[i] = false; break; }
+                }
+                // greedy walk
+                bool any = false;
+                for (int i = 0; i < NP; i++) {
+                    const uint32_t p = cur + i;
+                    if (p < pos || !take[i]) continue;
+                    uint32_t L = best[i];
+                    const uint32_t off = boff[i];
+                    if (L >= uint32_t(P->lane_cap)) {  // cooperative extension
+                        uint32_t end = pe;
+                        if (off > p) {
+                            const uint32_t q = uint32_t(base) + p - off;
+                            const uint32_t left = kTile - (q & (kTile - 1));
+                            if (p + left < end) end = p + left;
+                            while (p + L < end && s[p + L] == src[q + L]) L++;
+                        } else {
+                            while (p + L < end && s[p + L] == s[p - off + L]) L++;
+                        }
+                    }
+                    recs.push_back({p, L, off});
+                    pos = p + L; rep = off; any = true;
+                }
+                uint32_t next = cur + uint32_t(NP);
+                if (pos > next) next = pos & ~63u;
+                else if (!any && P->skip_shift) {
+                    uint32_t extra = (next - pos) >> P->skip_shift;
+                    if (extra > 7) extra = 7;
+                    next += 64u * uint32_t(NW) * extra;
+                }
+                cur = next;
+            }
+            // ---- serialize pass ----
+            const size_t o0 = o;
+            uint32_t prev_end = ps, prev_off = 0;
+            for (const Rec& r : recs) {
+                uint32_t bk = 0;
+                {
+                    uint32_t room = r.mp - prev_end;
+                    if (room > uint32_t(P->back)) room = uint32_t(P->back);
+                    uint32_t sroom;
+                    const uint8_t* a = s + r.mp;
+                    const uint8_t* b;
+                    if (r.off <= r.mp) { sroom = r.mp - r.off; b = s + r.mp - r.off; }
+                    else { const uint32_t q = uint32_t(base) + r.mp - r.off; sroom = q & (kTile - 1); b = src + q; }
+                    if (room > sroom) room = sroom;
+                    if (uint32_t(base) + r.mp - r.off < 8) room = 0;  // the kernel compares the 8 bytes before both positions
+                    while (bk < room && a[-1 - int(bk)] == b[-1 - int(bk)]) bk++;
+                }
+                const uint32_t ms = r.mp - bk, len = r.len + bk;
+                const uint32_t lits = ms - prev_end;
+                const bool is_rep = r.off == prev_off;
+                const Emit e = plan_emit(lits, r.off, len, is_rep);
+                for (uint32_t k = 0; k < e.pre.n; k++) out[o++] = uint8_t(e.pre.bits >> (8 * k));
+                memcpy(out + o, s + prev_end, lits); o += lits;
+                for (uint32_t k = 0; k < e.post.n; k++) out[o++] = uint8_t(e.post.bits >> (8 * k));
+                if (stats) { stats[0]++; stats[1] += lits; if (r.off > r.mp) stats[2]++; if (is_rep) stats[3]++; }
+                prev_end = ms + len; prev_off = r.off;
+            }
+            if (prev_end < pe) {
+                const uint32_t lits = pe - prev_end;
+                const Hdr h = lit_header(lits);
+                for (uint32_t k = 0; k < h.n; k++) out[o++] = uint8_t(h.bits >> (8 * k));
+                memcpy(out + o, s + prev_end, lits); o += lits;
+                if (stats) stats[1] += lits;
+            }
+            const uint32_t plen = pe - ps;
+            const uint32_t raw = lit_header(plen).n + plen;
+            if (o - o0 >= raw) {  // piece stored as one literal run
+                o = o0;
+                const Hdr h = lit_header(plen);
+                for (uint32_t k = 0; k < h.n; k++) out[o++] = uint8_t(h.bits >> (8 * k));
+                memcpy(out + o, s + ps, plen); o += plen;
+            }
+        }
+    }
+    return o;
+}
+
+}  // extern "C"

@@ -772,6 +772,17 @@ int64_t mlz_crc(mlz_ctx* c, const uint8_t* src, size_t n) {
     return int64_t(v);
 }
 
+#ifdef MLZ_M2_PROF
+// debug build only (tools/m2prof.py): per-phase cycle sums of match_tiles_kernel; reset after reading
+int mlz_debug_m2prof(unsigned long long* out) {
+    if (hipDeviceSynchronize() != hipSuccess) return -MLZ_ERR_HIP;
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(mlz::g_m2prof), sizeof(unsigned long long) * 16) != hipSuccess) return -MLZ_ERR_HIP;
+    unsigned long long z[16] = {};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(mlz::g_m2prof), z, sizeof(z)) != hipSuccess) return -MLZ_ERR_HIP;
+    return 0;
+}
+#endif
+
 }  // extern "C"
 
 #include "mlz_stream.hip.inc"

@@ -33,7 +33,17 @@ inline uint64_t ld64z(const uint8_t* s, size_t p, size_t n) {  // bytes past n r
 }
 inline uint32_t hash4(uint64_t v, int bits) { return (uint32_t(v) * 2654435761u) >> (32 - bits); }
 struct FarHash { uint32_t idx, tag; };
+static int g_hash24 = 0;
+inline uint32_t mul24(uint32_t a, uint32_t b) { return (a & 0xffffffu) * (b & 0xffffffu); }
 inline FarHash far_hash(uint64_t v, int bits) {
+    if (g_hash24) {
+        const uint32_t lo = uint32_t(v), hi = uint32_t(v >> 32);
+        uint32_t a = mul24(lo, 0x9E3779u);
+        a += mul24(lo >> 8, 0x85EBCBu);
+        a += mul24(hi, 0xC2B2AFu);
+        a += mul24(hi >> 8, 0x27D4EBu);
+        return {a >> (32 - bits), (a >> (32 - bits - kFarTagBits)) & kFarTagMask};
+    }
     const uint32_t h = (uint32_t(v) * 0x9E3779B1u) ^ (uint32_t(v >> 32) * 0x85EBCA77u);
     const uint32_t g = h * 0xC2B2AE3Du;
     return {g >> (32 - bits), (g >> (32 - bits - kFarTagBits)) & kFarTagMask};
@@ -56,6 +66,10 @@ struct Params {
     int seed;       // 1: pre-seed the near table with the tile's earlier positions
     int lazy_cost;  // 1: lazy compares length minus token size
     int min_far;    // minimum far match (8)
+    int probe_stride; // 1: every position is probed; 2: only even positions are (all positions are still inserted); experiment
+    int far_stride2;  // experiment: far probes only at even positions
+    int lazy_local;   // 1: the look-ahead does not cross a 64-position window
+    int far_hash24;   // 1: far hash from 24-bit multiply-adds
 };
 
 struct Rec { uint32_t mp, len, off; };
@@ -65,6 +79,7 @@ extern "C" {
 // Encodes one block; writes the token stream (no block header) to out (cap >= n + n/8 + 64); returns its size.
 // stats[0] = tokens, [1] = literal bytes, [2] = far tokens, [3] = repeat tokens, [4] = windows probed
 size_t model2_block(const uint8_t* src, size_t n, const Params* P, uint8_t* out, uint64_t* stats) {
+    g_hash24 = P->far_hash24;
     const uint32_t pat = P->dense ? kPatternDense : kPatternFast;
     const size_t ntiles = (n + kTile - 1) >> kTileLog;
     const size_t nepoch = (n + (size_t(1) << kEpochLog) - 1) >> kEpochLog;
@@ -104,9 +119,17 @@ size_t model2_block(const uint8_t* src, size_t n, const Params* P, uint8_t* out,
                     table[h1 >> 1] = uint16_t(p | ((h1 & 1) << 15));
                 }
             uint32_t cur = ps, pos = ps, rep = 0;
+            // the kernel's far pipeline: candidates exist for an iteration only if its windows were the expected ones
+            // two iterations earlier (table entries) and one iteration earlier (candidate bytes); the two start-up trips
+            // fill it for the piece's first windows
+            const uint32_t kNone = 0xffffffffu;
+            uint32_t pf_cur = kNone, cand_cur = kNone;
+            if (far_tile) { pf_cur = ps; cand_cur = ps; pf_cur = ps + uint32_t(W * NW); }
             while (cur + 4 <= pe) {
-                uint32_t best[128], boff[128];
-                bool valid[128];
+                const bool use_far = far_tile && cand_cur == cur;
+                if (far_tile) { const uint32_t nx = cur + uint32_t(W * NW); if (pf_cur == nx) cand_cur = nx; pf_cur = nx + uint32_t(W * NW); }
+                uint32_t best[256], boff[256];
+                bool valid[256];
                 const int NP = W * NW;
                 for (int w = 0; w < NW; w++) {
                     uint32_t e[64], hh[64], tg[64];
@@ -123,6 +146,7 @@ size_t model2_block(const uint8_t* src, size_t n, const Params* P, uint8_t* out,
                         const uint32_t p = cur + i;
                         best[i] = 0; boff[i] = 0;
                         if (!valid[i]) continue;
+                        if (P->probe_stride > 1 && (p & uint32_t(P->probe_stride - 1))) continue;
                         if (stats) stats[4]++;
                         const uint64_t v = ld64z(s, p, tl);
                         const uint32_t maxl = pe - p;
@@ -141,7 +165,7 @@ size_t model2_block(const uint8_t* src, size_t n, const Params* P, uint8_t* out,
                             b = k;
                         }
                         if (b > maxl) b = maxl;
-                        if (far_tile && !(P->far_gate && b >= 8)) {
+                        if (use_far && !(P->far_gate && b >= 8) && !(P->far_stride2 && (p & 1))) {
                             const FarHash fh = far_hash(v, kFarBits);
                             const size_t ep = (base + p) >> kEpochLog;
                             const uint32_t en = ftab[(ep << kFarBits) + fh.idx];
@@ -151,7 +175,8 @@ size_t model2_block(const uint8_t* src, size_t n, const Params* P, uint8_t* out,
                                 const uint32_t left = kTile - (fq & (kTile - 1));
                                 if (fq < base && off <= kMaxCopy3Offset && left >= 8) {
                                     uint64_t fv; memcpy(&fv, src + fq, 8);
-                                    if (fv == v && maxl >= 8) {
+                                    const bool deep = base + p + 40 <= n;  // the kernel looks at a far candidate only when 32 bytes are readable on both sides
+                                    if (fv == v && maxl >= 8 && deep) {
                                         const uint32_t lm = left < lim ? left : lim;
                                         uint32_t k = 8;
                                         while (k < lm && s[p + k] == src[fq + k]) k++;
@@ -165,7 +190,7 @@ size_t model2_block(const uint8_t* src, size_t n, const Params* P, uint8_t* out,
                     }
                 }
                 // lazy
-                bool take[128];
+                bool take[256];
                 for (int i = 0; i < NP; i++) {
                     take[i] = best[i] >= 4;
                     if (!take[i]) continue;
@@ -173,7 +198,7 @@ size_t model2_block(const uint8_t* src, size_t n, const Params* P, uint8_t* out,
                         if (!P->lazy_cost || best[j] < 4) return best[j];
                         return best[j] - (boff[j] > kMaxCopy2Offset ? 4u : boff[j] > kMaxCopy1Offset ? 3u : 2u);
                     };
-                    for (int k = 1; k <= P->lazy && i + k < NP; k++)
+                    for (int k = 1; k <= P->lazy && i + k < NP && !(P->lazy_local && (i & 63) + k >= 64); k++)
                         if (gain(i + k) > gain(i) + uint32_t(k - 1)) { take[i] = false; break; }
                 }
                 // greedy walk

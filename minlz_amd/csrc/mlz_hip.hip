@@ -94,6 +94,8 @@ struct mlz_ctx {
     // decode workspace
     DevBuf d_dec, d_idx;
     int general_algo = 0;  // 0 = pointer-jumping pass for general blocks, 1 = tile chain in the exec pass
+    int gen_grid = 0;      // workgroups of the persistent general-block launch (one per CU)
+    uint32_t gen_spin_limit = 1u << 24;  // grid-barrier patience in polls (~0.3 us each): ~5 s
     int n_cus = 0;
     // host-pointer staging
     DevBuf d_in, d_out, d_len, d_crc;
@@ -168,7 +170,8 @@ int upload_blocks(mlz_ctx* c, hipStream_t st, const mlz_block_desc* desc, int n,
         b.first_seg = segs;
         b.n_segs = 0;
         if (tiles_from_dst) {  // decode: segments of the token stream
-            uint64_t cl = std::min<uint64_t>(desc[i].src_len, uint64_t(kMaxBlockSize) + 16);
+            // a valid token stream is at most twice its output (dec_header_kernel rejects longer ones before any pass walks them)
+            uint64_t cl = std::min<uint64_t>(desc[i].src_len, 2 * std::min<uint64_t>(desc[i].dst_cap, kMaxBlockSize) + 32);
             b.n_segs = uint32_t((cl + kSeg - 1) >> kSegLog);
             segs += b.n_segs;
         }
@@ -389,10 +392,17 @@ int decode_parallel(mlz_ctx* c, hipStream_t st, const uint8_t* d_src, uint8_t* d
         if (jump && segs) {  // returns at once unless D3c flagged a general block
             if (!c->gen_attr) {
                 HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(dec_general_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kGenLds));
+                // the persistent launch needs every workgroup resident at once: size it from the occupancy query
+                // (1024 threads + 128 KiB of LDS: one per CU, or none on a device that cannot hold it)
+                int per_cu = 0;
+                HIPCHK(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(dec_general_kernel), kGenThreads, kGenLds));
+                c->gen_grid = per_cu >= 1 ? c->n_cus : 0;
                 c->gen_attr = true;
             }
-            hipLaunchKernelGGL(dec_general_kernel, dim3(c->n_cus), dim3(kGenThreads), kGenLds, st, d_src, d_dst, blocks, seg_block, tile_block, dec, tok_mask,
-                               chunk_d, chunk_rep, tile_start, c->d_idx.as<uint32_t>(), c->d_idx.as<uint8_t>() + idx_bytes, gen, segs, tiles, uint32_t(n));
+            if (c->gen_grid == 0) { c->err = "dec_general_kernel: the device cannot hold one workgroup per CU"; return -MLZ_ERR_HIP; }
+            hipLaunchKernelGGL(dec_general_kernel, dim3(c->gen_grid), dim3(kGenThreads), kGenLds, st, d_src, d_dst, blocks, seg_block, tile_block, dec, tok_mask,
+                               chunk_d, chunk_rep, tile_start, c->d_idx.as<uint32_t>(), c->d_idx.as<uint8_t>() + idx_bytes, gen, segs, tiles, uint32_t(n),
+                               c->gen_spin_limit);
         }
         hipLaunchKernelGGL(dec_finish_kernel, dim3((n + 63) / 64), dim3(64), 0, st, dec, d_out_len, n, c->debug_status);
     }
@@ -680,6 +690,7 @@ int mlz_set_option(mlz_ctx* c, int opt, int64_t value) {
     case MLZ_OPT_DECODE_ALGO: c->decode_algo = int(value); return 0;
     case MLZ_OPT_ENCODE_FAR: c->encode_far = int(value); return 0;
     case 8: c->general_algo = int(value); return 0;  // 0 = pointer-jumping pass for general blocks (default), 1 = tile chain
+    case 9: c->gen_spin_limit = value > 0 ? uint32_t(value) : 1u; return 0;  // grid-barrier patience of the general-block pass, in polls (tests)
     case 6: c->encode_algo = int(value); return 0;  // 0 = match + serialize kernels (default), 2 = the round-1 wave-per-tile kernel at LevelFastest / LevelSuperFast
     case 3: c->debug_status = int(value); return 0;  // debug: report failure sites in the error code
     case 4: {  // debug: per-phase cycle counters (16 x u64: 0-7 encode, 8-15 decode)

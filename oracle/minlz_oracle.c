@@ -614,6 +614,131 @@ static inline long l3_copy_size(long offset, long length) { /* emitCopySize, enc
 }
 static inline uint32_t hash8(uint64_t u, unsigned h) { return (uint32_t)((u * 0xcf1bbcdcb7a56463ull) >> (64 - h)); }
 
+/*
+ * L0 "SuperFast".  encodeFastBlockGo (encode_l0.go:32-279; BIG=1: hash8, 13 bits, u32 entries, skipLog 5,
+ * nextS + 5, dstLimit n - n/8 - 6, <=3 fused literals, copy3 allowed, minSrcPos window check) and
+ * encodeFastBlockGo64K (encode_l0.go:281-522; BIG=0: 12 bits, u16 entries, skipLog 4, nextS + 4,
+ * dstLimit n - n/16 - 32, <=4 fused literals).  Differences from L1: 8-byte candidate checks, no backward
+ * extension (the loop is disabled upstream: `for false && ...`, encode_l0.go:133), forward extension from +8.
+ * The reference reads cv2 = load64(src, s+2) with s <= len-8, i.e. up to two bytes past the end of src through
+ * its unsafe loads (unsafe_enabled.go:42-46); this restatement reads those bytes as zero.
+ */
+static inline uint64_t ld64z(const uint8_t* src, long n, long i) {
+    if (i + 8 <= n) return ld64(src, i);
+    uint64_t v = 0;
+    if (i < n) memcpy(&v, src + i, (size_t)(n - i));
+    return v;
+}
+#define DEFINE_L0(NAME, BIG, TBITS, TTYPE, SKIPLOG, SKIPADD, DSTLIMIT, MAXLITS)                            \
+    static size_t NAME(uint8_t* dst, const uint8_t* src, long n) {                                         \
+        TTYPE* table = (TTYPE*)calloc((size_t)1 << TBITS, sizeof(TTYPE));                                  \
+        long sLimit = n - INPUT_MARGIN;                                                                    \
+        long dstLimit = DSTLIMIT;                                                                          \
+        long nextEmit = 0, s = 1, d = 0, repeat = 1;                                                       \
+        uint64_t cv = ld64(src, s);                                                                        \
+        for (;;) {                                                                                         \
+            long candidate = 0;                                                                            \
+            for (;;) {                                                                                     \
+                long nextS = s + ((s - nextEmit) >> SKIPLOG) + SKIPADD;                                    \
+                if (nextS > sLimit) goto emit_remainder;                                                   \
+                long minSrcPos = BIG ? s - MAX_COPY3_OFFSET : 0;                                           \
+                uint32_t h0 = hash8(cv, TBITS);                                                            \
+                uint64_t cv1 = ld64z(src, n, s + 1);                                                       \
+                uint32_t h1 = hash8(cv1, TBITS);                                                           \
+                candidate = (long)table[h0];                                                               \
+                long candidate2 = (long)table[h1];                                                         \
+                table[h0] = (TTYPE)s;                                                                      \
+                table[h1] = (TTYPE)(s + 1);                                                                \
+                uint64_t cv2 = ld64z(src, n, s + 2);                                                       \
+                uint32_t h2 = hash8(cv2, TBITS);                                                           \
+                if ((uint32_t)cv1 == ld32(src, s - repeat + 1)) {  /* checkRep = 1 */                      \
+                    long base = s + 1;                                                                     \
+                    for (long i = base - repeat; base > nextEmit && i > 0 && src[i - 1] == src[base - 1];) { i--; base--; } \
+                    if (d + (base - nextEmit) > dstLimit) { free(table); return 0; }                       \
+                    d += mlzo_emit_literal(dst + d, src + nextEmit, base - nextEmit);                      \
+                    long cand = s - repeat + 4 + 1;                                                        \
+                    s += 4 + 1;                                                                            \
+                    while (s <= sLimit) {                                                                  \
+                        uint64_t diff = ld64(src, s) ^ ld64(src, cand);                                    \
+                        if (diff) { s += ctz64(diff) >> 3; break; }                                        \
+                        s += 8; cand += 8;                                                                 \
+                    }                                                                                      \
+                    d += mlzo_emit_repeat(dst + d, s - base);                                              \
+                    nextEmit = s;                                                                          \
+                    if (s >= sLimit) goto emit_remainder;                                                  \
+                    cv = ld64(src, s);                                                                     \
+                    continue;                                                                              \
+                }                                                                                          \
+                if (candidate >= minSrcPos && cv == ld64(src, candidate)) break;                           \
+                candidate = (long)table[h2];                                                               \
+                if (candidate2 >= minSrcPos && cv1 == ld64(src, candidate2)) {                             \
+                    table[h2] = (TTYPE)(s + 2);                                                            \
+                    candidate = candidate2; s++;                                                           \
+                    break;                                                                                 \
+                }                                                                                          \
+                table[h2] = (TTYPE)(s + 2);                                                                \
+                if (candidate >= minSrcPos && cv2 == ld64(src, candidate)) { s += 2; break; }              \
+                cv = ld64(src, nextS);                                                                     \
+                s = nextS;                                                                                 \
+            }                                                                                              \
+            long base = s;                                                                                 \
+            repeat = base - candidate;                                                                     \
+            s = extend8(src, n, s + 8, candidate + 8);                                                     \
+            long length = s - base;                                                                        \
+            if (nextEmit != base) {                                                                        \
+                if (base - nextEmit > MAXLITS || repeat < MIN_COPY2_OFFSET) {                              \
+                    if (d + (s - nextEmit) > dstLimit) { free(table); return 0; }                          \
+                    d += mlzo_emit_literal(dst + d, src + nextEmit, base - nextEmit);                      \
+                    d += mlzo_emit_copy(dst + d, repeat, length);                                          \
+                } else if (!BIG || repeat <= MAX_COPY2_OFFSET) {                                           \
+                    d += mlzo_emit_copy_lits2(dst + d, src + nextEmit, base - nextEmit, repeat, length);   \
+                } else {                                                                                   \
+                    d += mlzo_emit_copy_lits3(dst + d, src + nextEmit, base - nextEmit, repeat, length);   \
+                }                                                                                          \
+            } else {                                                                                       \
+                d += mlzo_emit_copy(dst + d, repeat, length);                                              \
+            }                                                                                              \
+            for (;;) { /* immediate re-match loop */                                                       \
+                nextEmit = s;                                                                              \
+                if (s >= sLimit) goto emit_remainder;                                                      \
+                uint64_t x = ld64(src, s - 2);                                                             \
+                if (d > dstLimit) { free(table); return 0; }                                               \
+                uint32_t m2 = hash8(x, TBITS);                                                             \
+                x = ld64(src, s);                                                                          \
+                uint32_t cur = hash8(x, TBITS);                                                            \
+                candidate = (long)table[cur];                                                              \
+                table[m2] = (TTYPE)(s - 2);                                                                \
+                table[cur] = (TTYPE)s;                                                                     \
+                if ((BIG && s - candidate > MAX_COPY3_OFFSET) || x != ld64(src, candidate)) {              \
+                    cv = ld64z(src, n, s + 1);                                                             \
+                    s++;                                                                                   \
+                    break;                                                                                 \
+                }                                                                                          \
+                repeat = s - candidate;                                                                    \
+                base = s;                                                                                  \
+                s = extend8(src, n, s + 8, candidate + 8);                                                 \
+                d += mlzo_emit_copy(dst + d, repeat, s - base);                                            \
+            }                                                                                              \
+        }                                                                                                  \
+    emit_remainder:                                                                                        \
+        if (nextEmit < n) {                                                                                \
+            if (d + n - nextEmit > dstLimit) { free(table); return 0; }                                    \
+            d += mlzo_emit_literal(dst + d, src + nextEmit, n - nextEmit);                                 \
+        }                                                                                                  \
+        free(table);                                                                                       \
+        return (size_t)d;                                                                                  \
+    }
+
+DEFINE_L0(l0_big, 1, 13, uint32_t, 5, 5, n - (n >> 3) - 6, MAX_COPY3_LITS)
+DEFINE_L0(l0_64k, 0, 12, uint16_t, 4, 4, n - (n >> 4) - 32, MAX_COPY2_LITS)
+
+/* encodeBlockFast, asm_none.go:33-42 */
+size_t mlzo_encode_block_l0(uint8_t* dst, const uint8_t* src, size_t n) {
+    if (n < MIN_NON_LITERAL_BLOCK_SIZE) return 0;
+    if (n <= 65536) return l0_64k(dst, src, (long)n);
+    return l0_big(dst, src, (long)n);
+}
+
 typedef struct { const uint8_t* src; long n, sLimit, nextEmit; const l3match* best; } l3ctx;
 
 static long l3_score(const l3ctx* c, const l3match* m) { /* encode_l3.go:139-160 */
@@ -832,8 +957,9 @@ static long encode_uncompressed(uint8_t* dst, const uint8_t* src, size_t n) {
     return (long)n + 2;
 }
 
-/* Encode, encode.go:74-139.  Levels: 0 uncompressed, 1 fastest, 2 balanced, 3 smallest.
- * (LevelSuperFast -1 is not restated: SURVEY.md section 2 row 7.) */
+size_t mlzo_encode_block_l0(uint8_t* dst, const uint8_t* src, size_t n);
+
+/* Encode, encode.go:74-139.  Levels: -1 superfast, 0 uncompressed, 1 fastest, 2 balanced, 3 smallest. */
 long mlzo_encode(uint8_t* dst, size_t dcap, const uint8_t* src, size_t n, int level) {
     long maxlen = mlzo_max_encoded_len(n);
     if (maxlen < 0) return -MLZO_ERR_TOO_LARGE;
@@ -844,6 +970,7 @@ long mlzo_encode(uint8_t* dst, size_t dcap, const uint8_t* src, size_t n, int le
     size_t m;
     switch (level) {
     case 0: return encode_uncompressed(dst, src, n);
+    case -1: m = mlzo_encode_block_l0(dst + d, src, n); break;
     case 1: m = mlzo_encode_block_l1(dst + d, src, n); break;
     case 2: m = mlzo_encode_block_l2(dst + d, src, n); break;
     case 3: m = mlzo_encode_block_l3(dst + d, src, n); break;

@@ -62,6 +62,7 @@ size_t mlzo_emit_copy_lits3(uint8_t* dst, const uint8_t* lits, size_t nlits, siz
 /* MaxEncodedLen (encode.go:234-244): -1 when too large. */
 long mlzo_max_encoded_len(size_t n);
 /* encodeBlock / encodeBlockBetter (asm_none.go:51-76): token stream only, 0 = incompressible. */
+size_t mlzo_encode_block_l0(uint8_t* dst, const uint8_t* src, size_t n);  /* encodeBlockFast (LevelSuperFast), encode_l0.go */
 size_t mlzo_encode_block_l1(uint8_t* dst, const uint8_t* src, size_t n);
 size_t mlzo_encode_block_l2(uint8_t* dst, const uint8_t* src, size_t n);
 /* encodeBlockBest (encode_l3.go:38-625), no dictionary. */

@@ -47,6 +47,7 @@ def lib():
         L.mlzo_emit_copy_lits2.argtypes = [u8p, u8p, sz, sz, sz]; L.mlzo_emit_copy_lits2.restype = sz
         L.mlzo_emit_copy_lits3.argtypes = [u8p, u8p, sz, sz, sz]; L.mlzo_emit_copy_lits3.restype = sz
         L.mlzo_max_encoded_len.argtypes = [sz]; L.mlzo_max_encoded_len.restype = C.c_long
+        L.mlzo_encode_block_l0.argtypes = [u8p, u8p, sz]; L.mlzo_encode_block_l0.restype = sz
         L.mlzo_encode_block_l1.argtypes = [u8p, u8p, sz]; L.mlzo_encode_block_l1.restype = sz
         L.mlzo_encode_block_l2.argtypes = [u8p, u8p, sz]; L.mlzo_encode_block_l2.restype = sz
         L.mlzo_encode_block_l3.argtypes = [u8p, u8p, sz]; L.mlzo_encode_block_l3.restype = sz
@@ -120,7 +121,7 @@ def encode_block(src, level=1):
     """encodeBlock / encodeBlockBetter: token stream only; b'' = incompressible."""
     a, p, n = _buf(src)
     out = np.empty(n + 64, dtype=np.uint8)
-    f = {1: lib().mlzo_encode_block_l1, 2: lib().mlzo_encode_block_l2, 3: lib().mlzo_encode_block_l3}[level]
+    f = {-1: lib().mlzo_encode_block_l0, 1: lib().mlzo_encode_block_l1, 2: lib().mlzo_encode_block_l2, 3: lib().mlzo_encode_block_l3}[level]
     r = f(out.ctypes.data, p, n)
     return out[:r].tobytes()
 

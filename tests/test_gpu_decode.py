@@ -276,3 +276,60 @@ def test_many_general_blocks_take_the_tile_ordered_phase(ctx):
             assert ol[i] == -1 and O.decode_body(bytes(bad[body0:]), len(blocks[7]))[0] == 1   # ErrCorrupt, like the oracle
         else:
             assert ol[i] == len(blocks[i]) and outs[i].tobytes() == blocks[i]
+
+
+def test_general_block_barrier_is_bounded(ctx):
+    # The pass for general blocks (streams of the reference's own encoders) is one persistent launch with grid
+    # barriers.  Co-residency of its workgroups is sized from the occupancy query but is not a promise (another process,
+    # a CU mask), so the barrier's wait is bounded.  With the patience cut to a single poll the first barrier cannot
+    # complete (the workgroups leave phase E microseconds apart): the call must come back with ErrHIP — the Go wrapper's
+    # cue to fall back to its CPU path, INTEGRATION.md — instead of hanging, and with the default patience restored the
+    # same call must decode normally.
+    d = synth.text_like(3 << 20, 17)
+    ref = O.encode(d, 1)                      # reference-algorithm stream: a general block
+    assert mz.Decode(ref, ctx) == d.tobytes()
+    assert ctx.general_blocks() == 1          # it did take the general path
+    ctx.set_option(9, 1)
+    try:
+        with pytest.raises(mz.ErrHIP):
+            mz.Decode(ref, ctx)
+    finally:
+        ctx.set_option(9, 1 << 24)
+    assert mz.Decode(ref, ctx) == d.tobytes()
+    # a batch with one general and one conformant block: only the general one fails
+    own = mz.Encode(d, 1, ctx)
+    ctx.set_option(9, 1)
+    try:
+        with pytest.raises(mz.ErrHIP):
+            mz.decode_batch([own, ref], ctx)
+    finally:
+        ctx.set_option(9, 1 << 24)
+    assert mz.decode_batch([own, ref], ctx) == [d.tobytes(), d.tobytes()]
+
+
+def test_token_stream_longer_than_its_output(ctx):
+    # A stream of 1-byte literals is twice its output: 5 MiB of output from a 10 MiB body (more 8 KiB segments than an
+    # encoder's output for a full block ever has).
+    n = 5 << 20
+    d = synth.text_like(n, 23)
+    body = np.zeros(2 * n, dtype=np.uint8)
+    body[1::2] = d                              # tag 0x00 = literal of length 1, then the byte
+    hdr = bytearray([0])
+    v = n
+    while v >= 0x80:
+        hdr.append((v & 0x7f) | 0x80); v >>= 7
+    hdr.append(v)
+    blk = bytes(hdr) + body.tobytes()
+    # behind a block header such a body is refused outright (isMinLZ: decoded size < body size, decode.go:150-152) ...
+    with pytest.raises(O.OracleError):
+        O.decode(blk)
+    with pytest.raises(mz.ErrCorrupt):
+        mz.Decode(blk, ctx)
+    # ... but minLZDecode itself (the WriterCustomEncoder-side entry, mlz_decode_block) takes any src length
+    assert O.decode_body(body.tobytes(), n) == (0, d.tobytes())
+    assert mz.decode_block(body.tobytes(), n, ctx) == (0, d.tobytes())
+    # longer than 2 x dlen: no valid stream can be; same verdict as the reference's walk (decode.go:615)
+    bad = body.tobytes() + bytes(64)
+    assert O.decode_body(bad, n)[0] != 0
+    assert mz.decode_block(bad, n, ctx)[0] == 1
+    assert mz.decode_block(bytes(9 << 20), 100, ctx)[0] == 1

@@ -13,10 +13,15 @@ from tests.util import load_zip
 pytestmark = pytest.mark.gpu
 
 # Stated ratio tolerances (DESIGN.md "Ratio"), on text-like and JSON-like 8 MiB blocks:
-#   LevelFastest : C_gpu(1) <= RATIO_TOL    * C_oracle(L1)   (measured 1.03 / 1.05)
-#   LevelBalanced: C_gpu(2) <= RATIO_TOL_L2 * C_oracle(L2)   (measured 1.08 / 1.10), and C_gpu(2) <= C_gpu(1)
-RATIO_TOL = 1.15
-RATIO_TOL_L2 = 1.15
+#   LevelFastest  : C_gpu(1)  <= RATIO_TOL    * C_oracle(L1)   (measured 1.03 / 1.05)
+#   LevelBalanced : C_gpu(2)  <= RATIO_TOL_L2 * C_oracle(L2)   (measured 1.08 / 1.10), and C_gpu(2) <= C_gpu(1)
+#   LevelSuperFast: C_gpu(-1) <= RATIO_TOL_L0 * C_oracle(L0)   (measured 0.90 / 0.87: 4-byte matches against the reference's 8)
+# and on 64 KiB blocks (the reference's small-block classes, encode_l1.go:285-524 / encode_l0.go:281-522):
+#   C_gpu(1) <= RATIO_TOL_64K * C_oracle(L1)
+RATIO_TOL = 1.08
+RATIO_TOL_L2 = 1.12
+RATIO_TOL_L0 = 1.00
+RATIO_TOL_64K = 1.08
 
 
 def roundtrip(d, ctx, level=1):
@@ -258,3 +263,59 @@ def test_concurrent_single_block_calls(ctx):
     b1, r1 = ctx.combine_stats()
     assert r1 - r0 == 96
     assert b1 - b0 < 96          # at least some calls shared a launch
+
+
+def test_config1_tom_sawyer(ctx, twain, twain_mzb):
+    # BASELINE config 1: testdata/Mark.Twain-Tom.Sawyer.txt as a single block (minlz_test.go:626-660 holds its
+    # LevelSmallest encoding).  Encode leg on the HIP path at every device level, decode leg with every decode pass.
+    for level, tol in ((mz.LevelFastest, RATIO_TOL), (mz.LevelBalanced, RATIO_TOL_L2), (mz.LevelSuperFast, RATIO_TOL_L0)):
+        enc = roundtrip(twain, ctx, level=level)
+        ref = O.encode(twain, level)
+        assert len(enc) <= tol * len(ref), (level, len(enc), len(ref))
+        assert mz.Decode(enc, ctx, guard=64) == twain
+    for algo in (0, 3, 1):
+        ctx.set_option(mz.OPT_DECODE_ALGO, algo)
+        try:
+            assert mz.Decode(twain_mzb, ctx, guard=64) == twain
+        finally:
+            ctx.set_option(mz.OPT_DECODE_ALGO, 0)
+
+
+@pytest.mark.parametrize("kind", ["text", "json"])
+def test_level_superfast_ratio(ctx, kind):
+    # LevelSuperFast against the oracle's restatement of encode_l0.go on 8 MiB blocks
+    d = synth.text_like(8 << 20, 1) if kind == "text" else synth.json_like(8 << 20)
+    enc = roundtrip(d, ctx, level=mz.LevelSuperFast)
+    ref = O.encode(d, -1)
+    assert len(enc) <= RATIO_TOL_L0 * len(ref), (len(enc), len(ref))
+
+
+def test_small_block_classes_ratio(ctx):
+    # 512 x 64 KiB text blocks in one batch (config-5 block size): every block round-trips through the oracle decoder and
+    # the batch stays within tolerance of the oracle's <= 64 KiB size classes at LevelFastest and LevelSuperFast
+    d = synth.text_like(512 * 65536, 12)
+    blocks = [d[i:i + 65536].tobytes() for i in range(0, d.size, 65536)]
+    for level, tol in ((mz.LevelFastest, RATIO_TOL_64K), (mz.LevelSuperFast, RATIO_TOL_L0)):
+        encs = mz.encode_batch(blocks, level, ctx)
+        for b, e in zip(blocks[::16], encs[::16]):
+            assert O.decode(e) == b
+        assert mz.decode_batch(encs, ctx) == blocks
+        c_gpu = sum(len(e) for e in encs)
+        c_ref = sum(len(O.encode(b, level)) for b in blocks)
+        assert c_gpu <= tol * c_ref, (level, c_gpu, c_ref)
+
+
+def test_incompressible_8mib_block(ctx):
+    # BASELINE config 4 at block size: an incompressible 8 MiB block takes the stored path (encode.go:137-138) and
+    # decodes back on the device
+    r = synth.random_bytes(8 << 20, seed=11)
+    enc = mz.Encode(r, mz.LevelFastest, ctx)
+    assert len(enc) == r.size + 2 and enc[:2] == b"\x00\x00"
+    assert bytes(enc[2:]) == r.tobytes()
+    assert mz.Decode(enc, ctx, guard=64) == r.tobytes()
+    assert mz.encode_block(r, mz.LevelFastest, ctx) == b""
+    # half noise, half text: compresses, and the noise tiles are stored as literal runs
+    mix = np.concatenate([r[:4 << 20], synth.text_like(4 << 20, 2)])
+    e = roundtrip(mix, ctx)
+    assert len(e) < mix.size * 0.75
+    assert mz.Decode(e, ctx) == mix.tobytes()

@@ -8,7 +8,7 @@ from minlz_amd import synth
 from tests.util import load_zip
 
 
-@pytest.mark.parametrize("level", [1, 2, 3])
+@pytest.mark.parametrize("level", [-1, 1, 2, 3])
 def test_enc_regressions_roundtrip(level):
     # testdata/enc_regressions.zip (decode_asm_test.go:49-73, writer_test.go:31-72)
     items = load_zip("enc_regressions.zip")
@@ -32,7 +32,7 @@ def test_block_corpus_enc_roundtrip():
 def test_patterns_roundtrip(name):
     for size in (17, 100, 4096, 65535, 65536, 65549, 70000, 300000):
         d = synth.pattern(name, size)
-        for level in (0, 1, 2):
+        for level in (-1, 0, 1, 2):
             assert O.decode(O.encode(d, level)) == d.tobytes()
 
 
@@ -41,7 +41,7 @@ def test_small_and_margin_sizes():
     for size in list(range(0, 40)) + [50, 60, 70, 80]:
         for pat in (b"a", b"ab", b"abcd"):
             d = (pat * (size // len(pat) + 1))[:size]
-            for level in (1, 2):
+            for level in (-1, 1, 2):
                 assert O.decode(O.encode(d, level)) == d
 
 
@@ -108,3 +108,15 @@ def test_l3_stream_64k_blocks():
     st = O.stream_encode(d, 3, 64 << 10)
     assert O.stream_decode(st, d.size) == d.tobytes()
     assert len(st) <= len(O.stream_encode(d, 2, 64 << 10))
+
+
+def test_level_superfast_restatement():
+    # encodeBlockFast (encode_l0.go): 8-byte minimum matches -> larger than L1, smaller than the input on text;
+    # both size classes (<= 64 KiB: encodeFastBlockGo64K, else encodeFastBlockGo), asm_none.go:33-42
+    for n in (65536, 65537, 1 << 20):
+        d = synth.text_like(n, 9)
+        e0, e1 = O.encode(d, -1), O.encode(d, 1)
+        assert O.decode(e0, guard=32) == d.tobytes()
+        assert len(e1) < len(e0) < n
+    d = synth.random_bytes(70000)
+    assert O.encode(d, -1) == b"\x00\x00" + d.tobytes()

@@ -91,7 +91,10 @@ int mlz_decode_batch(mlz_ctx* ctx, int n_blocks, const uint8_t* const* src, cons
 
 /* ---- device-resident batch calls (asynchronous on `stream`, a hipStream_t; NULL = default) ----
  * d_src / d_dst / d_out_len are device pointers.  d_out_len[i] (int64) receives what
- * mlz_encode / mlz_decode would have returned for block i.  `desc` is a host array (copied). */
+ * mlz_encode / mlz_decode would have returned for block i.  `desc` is a host array (copied).
+ * A context owns ONE workspace: calls issued on different streams are ordered on the device (each waits for the
+ * previous call's last kernel through an event), so they are safe but do not overlap; use one context per stream
+ * for concurrency. */
 int mlz_encode_batch_device(mlz_ctx* ctx, void* stream, int level, const uint8_t* d_src, uint8_t* d_dst,
                             const mlz_block_desc* desc, int n_blocks, int64_t* d_out_len);
 int mlz_decode_batch_device(mlz_ctx* ctx, void* stream, const uint8_t* d_src, uint8_t* d_dst,

@@ -89,6 +89,11 @@ struct mlz_ctx {
     size_t pinned_cap = 0;
     hipEvent_t upload_done = nullptr;
     bool upload_pending = false;
+    // One workspace serves every call on this context: a call on another stream first waits (on the device) for the
+    // previous call's last launch, so descriptors, scratch and flags are never shared by two calls in flight.
+    hipEvent_t ws_done = nullptr;
+    hipStream_t ws_stream = nullptr;
+    bool ws_used = false;
     // encode workspace
     DevBuf d_scratch, d_tile_size, d_tile_out, d_flags, d_far, d_recs, d_piece_cnt;
     // decode workspace
@@ -155,6 +160,19 @@ struct Timer {
     }
 };
 
+// Orders the calls that share the context's workspace across streams (see mlz_ctx::ws_done).
+struct WorkspaceOrder {
+    mlz_ctx* c; hipStream_t s;
+    WorkspaceOrder(mlz_ctx* c_, hipStream_t s_) : c(c_), s(s_) {
+        if (c->ws_used && c->ws_stream != s) (void)hipStreamWaitEvent(s, c->ws_done, 0);
+    }
+    ~WorkspaceOrder() {
+        (void)hipEventRecord(c->ws_done, s);
+        c->ws_stream = s;
+        c->ws_used = true;
+    }
+};
+
 // Builds BlockInfo / tile map on the host and uploads them when they differ from the last call.
 int upload_blocks(mlz_ctx* c, hipStream_t st, const mlz_block_desc* desc, int n, bool tiles_from_dst, uint32_t* total_tiles, uint32_t* total_segs = nullptr) {
     c->h_blocks.resize(n);
@@ -215,6 +233,7 @@ int encode_device_locked(mlz_ctx* c, hipStream_t st, int level, const uint8_t* d
     if (!valid_level(level)) return -MLZ_ERR_INVALID_LEVEL;
     if (n <= 0) return 0;
     HIPCHK(c, hipSetDevice(c->device));
+    WorkspaceOrder order(c, st);
     uint32_t tiles = 0;
     int r = upload_blocks(c, st, desc, n, false, &tiles);
     if (r) return r;
@@ -414,6 +433,7 @@ int decode_device_locked(mlz_ctx* c, hipStream_t st, const uint8_t* d_src, uint8
                          bool raw_body) {
     if (n <= 0) return 0;
     HIPCHK(c, hipSetDevice(c->device));
+    WorkspaceOrder order(c, st);
     if (c->decode_algo == 1) {
         uint32_t tiles = 0;
         int r = upload_blocks(c, st, desc, n, true, &tiles);
@@ -429,6 +449,7 @@ int decode_device_locked(mlz_ctx* c, hipStream_t st, const uint8_t* d_src, uint8
 int crc_device_locked(mlz_ctx* c, hipStream_t st, const uint8_t* d_base, const mlz_block_desc* desc, int n, uint32_t* d_out) {
     if (n <= 0) return 0;
     HIPCHK(c, hipSetDevice(c->device));
+    WorkspaceOrder order(c, st);
     uint32_t tiles = 0;
     int r = upload_blocks(c, st, desc, n, false, &tiles);
     if (r) return r;
@@ -552,6 +573,7 @@ int mlz_init(int device, mlz_ctx** out) {
     if (c->n_cus <= 0) c->n_cus = 64;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return -MLZ_ERR_HIP; }
     if (hipEventCreateWithFlags(&c->upload_done, hipEventDisableTiming) != hipSuccess) { delete c; return -MLZ_ERR_HIP; }
+    if (hipEventCreateWithFlags(&c->ws_done, hipEventDisableTiming) != hipSuccess) { delete c; return -MLZ_ERR_HIP; }
     for (int i = 0; i < T_COUNT; i++)
         for (int k = 0; k < 2; k++)
             if (hipEventCreate(&c->ev[i][k]) != hipSuccess) { delete c; return -MLZ_ERR_HIP; }
@@ -578,6 +600,7 @@ void mlz_destroy(mlz_ctx* c) {
         for (int k = 0; k < 2; k++)
             if (c->ev[i][k]) (void)hipEventDestroy(c->ev[i][k]);
     if (c->upload_done) (void)hipEventDestroy(c->upload_done);
+    if (c->ws_done) (void)hipEventDestroy(c->ws_done);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }

@@ -319,3 +319,33 @@ def test_incompressible_8mib_block(ctx):
     e = roundtrip(mix, ctx)
     assert len(e) < mix.size * 0.75
     assert mz.Decode(e, ctx) == mix.tobytes()
+
+
+def test_device_calls_on_two_streams_share_the_workspace(ctx):
+    # One context, two streams, different batches back to back without a host sync in between: the second call must
+    # wait (on the device) for the first one's kernels before it reuses descriptors, scratch and far tables.
+    import torch
+    from minlz_amd._lib import BlockDesc
+    dev = torch.device("cuda", 0)
+    s1, s2 = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+    a = synth.text_like(24 << 20, 41)
+    b_ = synth.json_like(8 << 20, 42)
+    A, B = torch.from_numpy(a).to(dev), torch.from_numpy(b_).to(dev)
+    blk = 8 << 20
+    stride = blk + 256
+    def desc(n):
+        k = (n + blk - 1) // blk
+        return (BlockDesc * k)(*[BlockDesc(i * blk, min(blk, n - i * blk), i * stride, stride) for i in range(k)]), k
+    da, ka = desc(a.size)
+    db, kb = desc(b_.size)
+    ea = torch.zeros(ka * stride, dtype=torch.uint8, device=dev); la = torch.zeros(ka, dtype=torch.int64, device=dev)
+    eb = torch.zeros(kb * stride, dtype=torch.uint8, device=dev); lb = torch.zeros(kb, dtype=torch.int64, device=dev)
+    torch.cuda.synchronize()
+    for _ in range(3):
+        ctx.encode_batch_device(s1.cuda_stream, 1, A.data_ptr(), ea.data_ptr(), da, la.data_ptr())
+        ctx.encode_batch_device(s2.cuda_stream, 1, B.data_ptr(), eb.data_ptr(), db, lb.data_ptr())
+    torch.cuda.synchronize()
+    ha, hb = ea.cpu().numpy(), eb.cpu().numpy()
+    out_a = b"".join(O.decode(ha[i * stride:i * stride + l].tobytes()) for i, l in enumerate(la.cpu().tolist()))
+    out_b = b"".join(O.decode(hb[i * stride:i * stride + l].tobytes()) for i, l in enumerate(lb.cpu().tolist()))
+    assert out_a == a.tobytes() and out_b == b_.tobytes()

@@ -1,24 +1,32 @@
 #!/usr/bin/env python3
 """bench.py — BASELINE.json metric: MB/s encode+decode, 8 MB blocks, LevelFastest, on N MI355X.
 
-One "step" = one pass of the hot path over one batch: encode every 8 MiB block of a per-GPU
-text-like stream (the enwik8 stand-in of SURVEY.md 8(d) config 2; enwik8 itself is not
-available offline) with the HIP encoder, then decode every block with the HIP decoder.  Inputs
-and outputs stay resident in HBM; the C ABI's device-resident batch calls are timed.
+One "step" = one pass of the hot path over one batch: encode every 8 MiB block of a per-GPU stream with the HIP
+encoder, then decode every block with the HIP decoder.  Inputs and outputs stay resident in HBM; the C ABI's
+device-resident batch calls are timed.  The stream is enwik8 when a path to it is given (--file / $MINLZ_BENCH_FILE;
+the file is not in the reference tree and there is no network), else a seeded stand-in that the reference's L1
+restatement compresses like text of that kind (ratio ~0.47; synth.enwik_like).  The easier round-1 stand-in
+(synth.text_like, ratio ~0.33) is measured beside it and reported under config.r01_standin.
 
     python bench.py --gpus 1 --steps 20 --warmup 3
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-Prints ONE JSON line on rank 0.  value = uncompressed bytes through the encode+decode pair per
-second, whole job (all ranks).  roofline = dominant kernel against HBM peak (algorithmic bytes
-N + C per launch / HIP-event launch time); cpu_baseline = the CPU oracle (a C restatement of the
-reference's pure-Go L1 encoder + decoder, NOT the reference's AMD64 asm) on this box's cores.
+Prints ONE JSON line on rank 0.  value = uncompressed bytes through the encode+decode pair per second, whole job
+(all ranks).  roofline = dominant kernel against HBM peak (algorithmic bytes N + C per launch / HIP-event launch
+time).  cpu_baseline = the CPU oracle (a C restatement of the reference's pure-Go L1 encoder + decoder, NOT the
+reference's AMD64 asm) on this box's cores: threads started and buffers touched before the clock, a sweep over
+thread counts with the best one reported, and the single-thread rate.  On rank 0 of a 1-GPU run the line also
+carries: config.decode_foreign_MBps (the same stream encoded by the reference's algorithm — every such stream
+takes the decoder's general path), config.end_to_end_MBps (pinned host memory -> mlz_encode_batch /
+mlz_decode_batch -> pinned host memory, PCIe included; never the headline value).
 """
 import argparse
 import ctypes as C
 import json
 import os
+import shutil
+import subprocess
 import sys
 import time
 
@@ -32,6 +40,78 @@ BLOCK = 8 << 20
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
 
 
+def usable_cpus():
+    """Threads this process may run on: the affinity mask, capped by a cgroup CPU quota when one is set."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]           # cgroup v2
+        if q != "max":
+            n = max(1, min(n, int(float(q) / float(p) + 0.5)))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())     # cgroup v1
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = max(1, min(n, int(q / p + 0.5)))
+        except Exception:
+            pass
+    return n
+
+
+def cpu_baseline(host, budget_s=20.0):
+    """The oracle's L1 encoder + decoder over 8 MiB blocks of the same stream, on the host cores."""
+    import oracle as O
+    sample = host[:min(host.size, 8 * BLOCK)]
+    ncpu = usable_cpus()
+    # single thread: the per-core rate (the reference quotes ~400 MB/s per core for L1 stream encode, README.md:203-212)
+    t1e, cb = O.bench_encode(sample[:2 * BLOCK], BLOCK, 1, 1, 1)
+    t1d = O.bench_decode(sample[:2 * BLOCK], BLOCK, 1, 1, 1)
+    per_core_e, per_core_d = 2 * BLOCK / 1e6 / t1e, 2 * BLOCK / 1e6 / t1d
+    spent = t1e + t1d
+    best = None
+    sweep = {}
+    th = 1
+    cand = []
+    while th < ncpu:
+        cand.append(th)
+        th *= 2
+    cand.append(ncpu)
+    for th in cand:
+        if th == 1:
+            rate_e, rate_d, reps = per_core_e, per_core_d, 1
+        else:
+            # enough (rep, block) items to keep every thread busy for several blocks' worth of time
+            reps = max(1, (4 * th + 7) // 8)
+            est = sample.size * reps / 1e6 * (1 / (per_core_e * min(th, 64)) + 1 / (per_core_d * min(th, 64)))
+            if spent + est > budget_s and best is not None:
+                break
+            te, _ = O.bench_encode(sample, BLOCK, 1, th, reps)
+            td = O.bench_decode(sample, BLOCK, 1, th, reps)
+            spent += te + td
+            rate_e, rate_d = sample.size * reps / 1e6 / te, sample.size * reps / 1e6 / td
+        pair = 1.0 / (1.0 / rate_e + 1.0 / rate_d)
+        sweep[str(th)] = round(pair, 1)
+        if best is None or pair > best[0]:
+            best = (pair, th, rate_e, rate_d, reps)
+    pair, th, rate_e, rate_d, reps = best
+    go = shutil.which("go")
+    go_note = None
+    if go:  # BASELINE.md section 3: the reference's own asm path is timed only when Go AND the upstream module are present
+        try:
+            go_note = subprocess.run([go, "version"], capture_output=True, text=True, timeout=20).stdout.strip()
+        except Exception:
+            go_note = "go present, version probe failed"
+    return {"value": round(pair, 1), "unit": "MB/s", "cores": th, "kind": "port",
+            "sample": "%d x 8 MiB blocks of the same stream, %d reps at the best thread count; C restatement of the reference's pure-Go L1 "
+                      "encoder + decoder (not its AMD64 asm); threads parked at a barrier with their buffers touched before the clock starts, "
+                      "blocks dealt from a shared counter" % (sample.size // BLOCK, reps),
+            "encode_MBps": round(rate_e, 1), "decode_MBps": round(rate_d, 1), "ratio": round(cb / (2 * BLOCK), 4),
+            "usable_cpus": ncpu, "thread_sweep_pair_MBps": sweep,
+            "per_core_MBps": {"encode": round(per_core_e, 1), "decode": round(per_core_d, 1)},
+            "reference_asm": ("not timed: %s, but the upstream module github.com/minio/minlz is not on this box (no network)" % go_note) if go
+                             else "not timed: `go` is not installed on this box (probed at run time)"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -40,9 +120,11 @@ def main():
     ap.add_argument("--bytes", type=int, default=100_000_000, help="uncompressed stream bytes per GPU (enwik8 = 1e8)")
     ap.add_argument("--level", type=int, default=1)
     ap.add_argument("--far", type=int, default=1)
-    ap.add_argument("--staged", type=int, default=-1, help="encoder variant: 0 in-place (default), 1 LDS-staged, 3 software-pipelined; -1 = library default")
+    ap.add_argument("--algo", type=int, default=-1, help="encoder variant (mlz_set_option 6): 0 match + serialize kernels, 2 round-1 wave-per-tile kernel; -1 = library default")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
-    ap.add_argument("--workload", default="text", choices=["text", "json", "random"])
+    ap.add_argument("--no-extras", action="store_true", help="skip the foreign-stream, end-to-end and round-1 stand-in legs")
+    ap.add_argument("--workload", default="enwik", choices=["enwik", "text", "json", "random"])
+    ap.add_argument("--file", default=os.environ.get("MINLZ_BENCH_FILE"), help="real input (e.g. enwik8); every rank reads its own --bytes slice, wrapping around")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -65,80 +147,104 @@ def main():
 
     ctx = mz.Context(local)
     ctx.set_option(mz.OPT_ENCODE_FAR, args.far)
-    if args.staged >= 0:
-        ctx.set_option(6, args.staged)
+    if args.algo >= 0:
+        ctx.set_option(6, args.algo)
 
-    # ---- synthetic stream for this rank (weak scaling: every rank has its own S bytes) ----
+    # ---- the stream of this rank (weak scaling: every rank has its own S bytes) ----
     S = args.bytes
-    gen = {"text": lambda: synth.text_like(S, seed=1 + rank), "json": lambda: synth.json_like(S, seed=77 + rank),
-           "random": lambda: synth.random_bytes(S, seed=5 + rank)}[args.workload]
-    host = gen()
-    nblk = (S + BLOCK - 1) // BLOCK
-    src = torch.from_numpy(host).to(dev)
-    stride = BLOCK + 256
-    enc = torch.empty(nblk * stride, dtype=torch.uint8, device=dev)
-    dec = torch.empty(S + 256, dtype=torch.uint8, device=dev)
-    enc_len = torch.zeros(nblk, dtype=torch.int64, device=dev)
-    dec_len = torch.zeros(nblk, dtype=torch.int64, device=dev)
-    blk_len = [min(BLOCK, S - i * BLOCK) for i in range(nblk)]
-    e_desc = (BlockDesc * nblk)(*[BlockDesc(i * BLOCK, blk_len[i], i * stride, stride) for i in range(nblk)])
+    if args.file:
+        raw = np.fromfile(args.file, dtype=np.uint8)
+        assert raw.size > 0, "empty --file"
+        start = (rank * S) % raw.size
+        host = np.resize(np.roll(raw, -start), S) if raw.size < start + S else raw[start:start + S].copy()
+        S = host.size
+        wname, data_kind = "file %s" % os.path.basename(args.file), "file"
+    else:
+        gen = {"enwik": lambda: synth.enwik_like(S, seed=1 + rank), "text": lambda: synth.text_like(S, seed=1 + rank),
+               "json": lambda: synth.json_like(S, seed=77 + rank), "random": lambda: synth.random_bytes(S, seed=5 + rank)}[args.workload]
+        host = gen()
+        wname = {"enwik": "enwik8-like synthetic text (the reference's L1 compresses it to ~0.47; enwik8 itself is not available offline)",
+                 "text": "round-1 text-like synthetic stream (phrase table; L1 ~0.33)", "json": "JSON-like synthetic records",
+                 "random": "incompressible bytes"}[args.workload]
+        data_kind = "synthetic"
     stream = torch.cuda.current_stream(dev).cuda_stream
 
-    def run_encode():
-        ctx.encode_batch_device(stream, args.level, src.data_ptr(), enc.data_ptr(), e_desc, enc_len.data_ptr())
+    class Leg:
+        """HBM-resident encode + decode of one stream through the device-resident batch calls."""
+        def __init__(self, data):
+            self.host = data
+            self.S = data.size
+            self.nblk = (self.S + BLOCK - 1) // BLOCK
+            self.src = torch.from_numpy(data).to(dev)
+            self.stride = BLOCK + 256
+            self.enc = torch.empty(self.nblk * self.stride, dtype=torch.uint8, device=dev)
+            self.dec = torch.empty(self.S + 256, dtype=torch.uint8, device=dev)
+            self.enc_len = torch.zeros(self.nblk, dtype=torch.int64, device=dev)
+            self.dec_len = torch.zeros(self.nblk, dtype=torch.int64, device=dev)
+            self.blk_len = [min(BLOCK, self.S - i * BLOCK) for i in range(self.nblk)]
+            self.e_desc = (BlockDesc * self.nblk)(*[BlockDesc(i * BLOCK, self.blk_len[i], i * self.stride, self.stride) for i in range(self.nblk)])
+            self.d_desc = None
+            self.clens = None
 
-    d_desc_box = [None]
+        def run_encode(self):
+            ctx.encode_batch_device(stream, args.level, self.src.data_ptr(), self.enc.data_ptr(), self.e_desc, self.enc_len.data_ptr())
 
-    def make_decode_desc():
-        lens = enc_len.cpu().tolist()
-        assert all(l > 0 for l in lens), lens
-        d_desc_box[0] = (BlockDesc * nblk)(*[BlockDesc(i * stride, lens[i], i * BLOCK, blk_len[i]) for i in range(nblk)])
-        return lens
+        def make_decode_desc(self, lens=None):
+            lens = lens if lens is not None else self.enc_len.cpu().tolist()
+            assert all(l > 0 for l in lens), lens
+            self.d_desc = (BlockDesc * self.nblk)(*[BlockDesc(i * self.stride, lens[i], i * BLOCK, self.blk_len[i]) for i in range(self.nblk)])
+            self.clens = lens
 
-    def run_decode():
-        ctx.decode_batch_device(stream, enc.data_ptr(), dec.data_ptr(), d_desc_box[0], dec_len.data_ptr())
+        def run_decode(self):
+            ctx.decode_batch_device(stream, self.enc.data_ptr(), self.dec.data_ptr(), self.d_desc, self.dec_len.data_ptr())
 
-    # ---- correctness outside the timed region ----
-    run_encode()
-    torch.cuda.synchronize(dev)
-    clens = make_decode_desc()
-    run_decode()
-    torch.cuda.synchronize(dev)
-    assert dec_len.cpu().tolist() == blk_len, "decode reported errors"
-    assert torch.equal(dec[:S], src), "GPU decode(encode(x)) != x"
-    C_total = sum(clens)
+        def check(self):
+            self.run_encode()
+            torch.cuda.synchronize(dev)
+            self.make_decode_desc()
+            self.run_decode()
+            torch.cuda.synchronize(dev)
+            assert self.dec_len.cpu().tolist() == self.blk_len, "decode reported errors"
+            assert torch.equal(self.dec[:self.S], self.src), "GPU decode(encode(x)) != x"
 
-    gathered = [torch.empty_like(enc_len) for _ in range(world)] if dist is not None else None
+        def timed(self, steps, warmup, collective=None):
+            """K steps bracketed by synchronize (+ barrier); returns (seconds, per-kernel HIP-event means in ms)."""
+            def step():
+                self.run_encode()
+                if collective is not None:
+                    collective(self.enc_len)
+                self.run_decode()
+            for _ in range(warmup):
+                step()
+            torch.cuda.synchronize(dev)
+            ctx.set_option(mz.OPT_TIMING, 2)   # running mean of the per-kernel HIP-event times, read once after the loop (no per-step sync)
+            if dist is not None:
+                dist.barrier()
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                step()
+            torch.cuda.synchronize(dev)
+            if dist is not None:
+                dist.barrier()
+            t1 = time.perf_counter()
+            kern = dict(ctx.timers())
+            ctx.set_option(mz.OPT_TIMING, 0)
+            return t1 - t0, kern
 
-    def step():
-        run_encode()
-        if dist is not None:
-            # the stream writer's only exchange: every rank learns every block's compressed size
-            # (output offsets / index, writer.go:223-243) — an RCCL all_gather of nblk int64
-            dist.all_gather(gathered, enc_len)
-        run_decode()
+    main_leg = Leg(host)
+    S, nblk = main_leg.S, main_leg.nblk
+    main_leg.check()                       # correctness outside the timed region
+    C_total = sum(main_leg.clens)
 
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize(dev)
+    gathered = [torch.empty_like(main_leg.enc_len) for _ in range(world)] if dist is not None else None
 
-    # ---- timed region: exactly K steps, barrier + synchronize on both sides ----
-    ctx.set_option(mz.OPT_TIMING, 2)   # running mean of the per-kernel HIP-event times; read once after the loop (no per-step sync)
-    kern = {}
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize(dev)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize(dev)
-    if dist is not None:
-        dist.barrier()
-    t1 = time.perf_counter()
-    elapsed = t1 - t0
-    for k, v in ctx.timers().items():  # HIP events recorded on the launch stream by the library, averaged over the K steps
-        kern[k] = [v]
-    ctx.set_option(mz.OPT_TIMING, 0)
+    def collective(enc_len):
+        # the stream writer's only exchange when every rank writes its own part: every rank learns every block's compressed size
+        # (output offsets / index, writer.go:223-243) — an RCCL all_gather of nblk int64
+        dist.all_gather(gathered, enc_len)
+
+    elapsed, kavg = main_leg.timed(args.steps, args.warmup, collective if dist is not None else None)
     if dist is not None:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -157,7 +263,6 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     total_bytes = S * world
     value = total_bytes / 1e6 / (elapsed / args.steps)
-    kavg = {k: float(np.mean(v)) for k, v in kern.items()}
     enc_ms = sum(v for k, v in kavg.items() if k.startswith("enc_"))
     dec_ms = sum(v for k, v in kavg.items() if k.startswith("dec_"))
     # dominant kernel and its roofline (algorithmic bytes per launch = N + C of this rank's batch)
@@ -172,30 +277,91 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tpath):
             tj = json.load(open(tpath))
-            kname = {"enc_tiles": "encode_tiles_kernel<true, false, %d>" % (2 if args.level == 2 else 1), "dec_exec": "dec_exec2_kernel", "enc_far_build": "far_build_kernel",
-                     "dec_parse": "dec_exit_kernel"}.get(dom)
-            if tj.get("workload_bytes") == S and args.workload == "text" and kname in tj.get("kernels", {}):
+            kname = {"enc_tiles": "match_tiles_kernel<true, 4>" if args.level != 2 and args.algo != 2 else "encode_tiles_kernel<true, false, %d>" % (2 if args.level == 2 else 1),
+                     "dec_exec": "dec_exec2_kernel", "enc_far_build": "far_build_kernel", "dec_parse": "dec_exit_kernel",
+                     "enc_serialize": "serialize_pieces_kernel"}.get(dom)
+            if tj.get("workload_bytes") == S and tj.get("workload", "text") == args.workload and not args.file and kname in tj.get("kernels", {}):
                 traffic = tj["kernels"][kname]["traffic"]
         roofline = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
                     "algorithmic_bytes_per_launch": alg, "avg_launch_ms": round(kavg[dom], 4)}
 
+    extras = {}
+    if world == 1 and not args.no_extras:
+        import oracle as O
+        # ---- foreign streams: the same data encoded by the reference's algorithm (oracle L1); decode only ----
+        lens = []
+        henc = np.zeros(main_leg.nblk * main_leg.stride, dtype=np.uint8)
+        for i in range(nblk):
+            e = O.encode(host[i * BLOCK:i * BLOCK + main_leg.blk_len[i]], 1)
+            henc[i * main_leg.stride:i * main_leg.stride + len(e)] = np.frombuffer(e, dtype=np.uint8)
+            lens.append(len(e))
+        main_leg.enc.copy_(torch.from_numpy(henc).to(dev))
+        main_leg.make_decode_desc(lens)
+        main_leg.run_decode()
+        torch.cuda.synchronize(dev)
+        assert main_leg.dec_len.cpu().tolist() == main_leg.blk_len and torch.equal(main_leg.dec[:S], main_leg.src), "decode of the reference-algorithm stream failed"
+        extras["decode_foreign_general_blocks"] = ctx.general_blocks()
+        for _ in range(2):
+            main_leg.run_decode()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(10):
+            main_leg.run_decode()
+        torch.cuda.synchronize(dev)
+        extras["decode_foreign_MBps"] = round(S / 1e6 / ((time.perf_counter() - t0) / 10), 1)
+        extras["decode_foreign_ratio"] = round(sum(lens) / S, 4)
+        # ---- end to end through the host-pointer ABI, pinned memory on both sides (PCIe included) ----
+        from minlz_amd import _lib
+        L = _lib.lib()
+        vp, sz = C.c_void_p, C.c_size_t
+        psrc = torch.empty(S, dtype=torch.uint8, pin_memory=True); psrc.numpy()[:] = host
+        penc = torch.empty(nblk * (BLOCK + 64), dtype=torch.uint8, pin_memory=True); penc.zero_()
+        pdec = torch.empty(S, dtype=torch.uint8, pin_memory=True); pdec.zero_()
+        sp = (vp * nblk)(*[psrc.data_ptr() + i * BLOCK for i in range(nblk)]); sl = (sz * nblk)(*main_leg.blk_len)
+        ep = (vp * nblk)(*[penc.data_ptr() + i * (BLOCK + 64) for i in range(nblk)]); ec = (sz * nblk)(*[BLOCK + 64] * nblk)
+        ol = (C.c_int64 * nblk)()
+        assert L.mlz_encode_batch(ctx.handle, args.level, nblk, sp, sl, ep, ec, ol) == 0
+        t0 = time.perf_counter()
+        for _ in range(5):
+            L.mlz_encode_batch(ctx.handle, args.level, nblk, sp, sl, ep, ec, ol)
+        te = (time.perf_counter() - t0) / 5
+        cl = (sz * nblk)(*[ol[i] for i in range(nblk)])
+        dp = (vp * nblk)(*[pdec.data_ptr() + i * BLOCK for i in range(nblk)]); dc = (sz * nblk)(*main_leg.blk_len)
+        dl = (C.c_int64 * nblk)()
+        assert L.mlz_decode_batch(ctx.handle, nblk, ep, cl, dp, dc, dl) == 0
+        t0 = time.perf_counter()
+        for _ in range(5):
+            L.mlz_decode_batch(ctx.handle, nblk, ep, cl, dp, dc, dl)
+        td = (time.perf_counter() - t0) / 5
+        assert bytes(pdec.numpy()) == host.tobytes()
+        extras["end_to_end_MBps"] = {"encode": round(S / 1e6 / te, 1), "decode": round(S / 1e6 / td, 1), "pair": round(S / 1e6 / (te + td), 1),
+                                     "note": "pinned host -> mlz_encode_batch / mlz_decode_batch -> pinned host, copies overlapped with kernels in 32 MiB groups"}
+        del psrc, penc, pdec
+        # ---- the round-1 stand-in, for continuity with BENCH_r01 ----
+        if args.workload == "enwik" and not args.file:
+            leg = Leg(synth.text_like(S, seed=1))
+            leg.check()
+            el, kk = leg.timed(max(3, args.steps // 2), 2)
+            e_ms = sum(v for k, v in kk.items() if k.startswith("enc_")); d_ms = sum(v for k, v in kk.items() if k.startswith("dec_"))
+            extras["r01_standin"] = {"workload": "synth.text_like (the round-1 bench stream)", "value_MBps": round(leg.S / 1e6 / (el / max(3, args.steps // 2)), 1),
+                                     "ratio": round(sum(leg.clens) / leg.S, 4), "encode_MBps": round(leg.S / 1e6 / (e_ms / 1e3), 1),
+                                     "decode_MBps": round(leg.S / 1e6 / (d_ms / 1e3), 1), "kernel_ms": {k: round(v, 4) for k, v in kk.items()}}
+            del leg
+
     cpu = None
     if not args.no_cpu and world == 1:   # the CPU leg runs on rank 0 of the single-GPU run only
-        import oracle as O
-        threads = os.cpu_count() or 1
-        sample = host[:min(S, 8 * BLOCK)]
-        # calibrate reps for ~10 s of CPU work
-        t_e, _ = O.bench_encode(sample, BLOCK, 1, threads, 1)
-        reps = max(1, min(50, int(5.0 / max(t_e, 1e-3))))
-        t_e, cbytes = O.bench_encode(sample, BLOCK, 1, threads, reps)
-        t_d = O.bench_decode(sample, BLOCK, 1, threads, reps)
-        cpu = {"value": round(sample.size * reps / 1e6 / (t_e + t_d), 1), "unit": "MB/s", "cores": threads, "kind": "port",
-               "sample": "%d x 8 MiB blocks of the same stream, %d reps, one block per thread; C restatement of the reference's pure-Go L1 "
-                         "encoder+decoder (not its AMD64 asm)" % (sample.size // BLOCK, reps),
-               "encode_MBps": round(sample.size * reps / 1e6 / t_e, 1), "decode_MBps": round(sample.size * reps / 1e6 / t_d, 1),
-               "ratio": round(cbytes / sample.size, 4)}
+        cpu = cpu_baseline(host)
 
+    cfg = {"workload": "%s, %d B per GPU in 8 MiB blocks (%d blocks), level %d, far=%d; step = encode all blocks + decode all blocks, HBM-resident"
+                       % (wname, S, nblk, args.level, args.far),
+           "block_size": BLOCK, "bytes_per_gpu": S, "ratio": round(C_all / total_bytes, 4),
+           "encode_MBps": round(S / 1e6 / (enc_ms / 1e3), 1) if enc_ms else None,
+           "decode_MBps": round(S / 1e6 / (dec_ms / 1e3), 1) if dec_ms else None,
+           "kernel_ms": {k: round(v, 4) for k, v in kavg.items()},
+           "hbm_read_frac_north_star": round((S / 1e9 / ((enc_ms + dec_ms) / 1e3)) / HBM_PEAK_GBS, 5) if enc_ms + dec_ms else None,
+           "device": ctx.device_name()}
+    cfg.update(extras)
     out = {
         "metric": "MB/s encode+decode, 8MB blocks L1",
         "value": round(value, 1),
@@ -208,15 +374,8 @@ def main():
         "scaling": "weak",
         "vs_baseline": None,
         "dtype": "u8",
-        "data": "synthetic",
-        "config": {"workload": "%s-like synthetic stream (enwik8 stand-in), %d B per GPU in 8 MiB blocks (%d blocks), level %d, far=%d; "
-                               "step = encode all blocks + decode all blocks, HBM-resident" % (args.workload, S, nblk, args.level, args.far),
-                   "block_size": BLOCK, "bytes_per_gpu": S, "ratio": round(C_all / total_bytes, 4),
-                   "encode_MBps": round(S / 1e6 / (enc_ms / 1e3), 1) if enc_ms else None,
-                   "decode_MBps": round(S / 1e6 / (dec_ms / 1e3), 1) if dec_ms else None,
-                   "kernel_ms": {k: round(v, 4) for k, v in kavg.items()},
-                   "hbm_read_frac_north_star": round((S / 1e9 / ((enc_ms + dec_ms) / 1e3)) / HBM_PEAK_GBS, 5) if enc_ms + dec_ms else None,
-                   "device": ctx.device_name()},
+        "data": data_kind,
+        "config": cfg,
         "roofline": roofline,
         "cpu_baseline": cpu,
     }

@@ -68,6 +68,8 @@ struct SingleReq {
     bool same_kind(const SingleReq& o) const { return encode == o.encode && with_header == o.with_header && has_dlen == o.has_dlen && level == o.level; }
 };
 
+constexpr size_t kHostGroupEncodeDefault = 32u << 20, kHostGroupDecodeDefault = 48u << 20;  // see host_batch
+
 struct mlz_ctx {
     int device = 0;
     std::mutex mu;
@@ -99,6 +101,7 @@ struct mlz_ctx {
     // decode workspace
     DevBuf d_dec, d_idx;
     int general_algo = 0;  // 0 = pointer-jumping pass for general blocks, 1 = tile chain in the exec pass
+    size_t host_group_enc = kHostGroupEncodeDefault, host_group_dec = kHostGroupDecodeDefault;  // host-pointer batches: bytes per overlapped group
     int gen_grid = 0;      // workgroups of the persistent general-block launch (one per CU)
     uint32_t gen_spin_limit = 1u << 24;  // grid-barrier patience in polls (~0.3 us each): ~5 s
     int n_cus = 0;
@@ -174,12 +177,14 @@ struct WorkspaceOrder {
 };
 
 // Builds BlockInfo / tile map on the host and uploads them when they differ from the last call.
-int upload_blocks(mlz_ctx* c, hipStream_t st, const mlz_block_desc* desc, int n, bool tiles_from_dst, uint32_t* total_tiles, uint32_t* total_segs = nullptr) {
+int upload_blocks(mlz_ctx* c, hipStream_t st, const mlz_block_desc* desc, int n, bool tiles_from_dst, uint32_t* total_tiles, uint32_t* total_segs = nullptr,
+                  const uint64_t* mirror = nullptr) {
     c->h_blocks.resize(n);
     uint32_t tiles = 0, segs = 0;
     for (int i = 0; i < n; i++) {
         BlockInfo& b = c->h_blocks[i];
         b.src_off = desc[i].src_off; b.src_len = desc[i].src_len; b.dst_off = desc[i].dst_off; b.dst_cap = desc[i].dst_cap;
+        b.mirror = mirror ? mirror[i] : 0;
         uint64_t span = tiles_from_dst ? desc[i].dst_cap : desc[i].src_len;
         if (span > kMaxBlockSize) span = tiles_from_dst ? kMaxBlockSize : 0;
         b.first_tile = tiles;
@@ -229,13 +234,13 @@ int upload_blocks(mlz_ctx* c, hipStream_t st, const mlz_block_desc* desc, int n,
 }
 
 int encode_device_locked(mlz_ctx* c, hipStream_t st, int level, const uint8_t* d_src, uint8_t* d_dst, const mlz_block_desc* desc, int n,
-                         int64_t* d_out_len, bool with_header) {
+                         int64_t* d_out_len, bool with_header, const uint64_t* mirror = nullptr) {
     if (!valid_level(level)) return -MLZ_ERR_INVALID_LEVEL;
     if (n <= 0) return 0;
     HIPCHK(c, hipSetDevice(c->device));
     WorkspaceOrder order(c, st);
     uint32_t tiles = 0;
-    int r = upload_blocks(c, st, desc, n, false, &tiles);
+    int r = upload_blocks(c, st, desc, n, false, &tiles, nullptr, mirror);
     if (r) return r;
     // LevelFastest / LevelSuperFast: match + serialize kernels on 8 KiB pieces (mlz_encode2.hip.inc);
     // LevelBalanced (and option 6 = 2): the wave-per-tile kernel of mlz_encode.hip.inc.
@@ -317,9 +322,9 @@ int encode_device_locked(mlz_ctx* c, hipStream_t st, int level, const uint8_t* d
 }
 
 int decode_parallel(mlz_ctx* c, hipStream_t st, const uint8_t* d_src, uint8_t* d_dst, const mlz_block_desc* desc, int n, int64_t* d_out_len,
-                    bool raw_body) {
+                    bool raw_body, const uint64_t* mirror) {
     uint32_t tiles = 0, segs = 0;
-    int r = upload_blocks(c, st, desc, n, true, &tiles, &segs);
+    int r = upload_blocks(c, st, desc, n, true, &tiles, &segs, mirror);
     if (r) return r;
     // carve the workspace
     auto al = [](size_t x) { return (x + 255) & ~size_t(255); };
@@ -430,7 +435,7 @@ int decode_parallel(mlz_ctx* c, hipStream_t st, const uint8_t* d_src, uint8_t* d
 }
 
 int decode_device_locked(mlz_ctx* c, hipStream_t st, const uint8_t* d_src, uint8_t* d_dst, const mlz_block_desc* desc, int n, int64_t* d_out_len,
-                         bool raw_body) {
+                         bool raw_body, const uint64_t* mirror = nullptr) {
     if (n <= 0) return 0;
     HIPCHK(c, hipSetDevice(c->device));
     WorkspaceOrder order(c, st);
@@ -443,7 +448,7 @@ int decode_device_locked(mlz_ctx* c, hipStream_t st, const uint8_t* d_src, uint8
         HIPCHK(c, hipGetLastError());
         return 0;
     }
-    return decode_parallel(c, st, d_src, d_dst, desc, n, d_out_len, raw_body);
+    return decode_parallel(c, st, d_src, d_dst, desc, n, d_out_len, raw_body, mirror);
 }
 
 int crc_device_locked(mlz_ctx* c, hipStream_t st, const uint8_t* d_base, const mlz_block_desc* desc, int n, uint32_t* d_out) {
@@ -473,12 +478,23 @@ int crc_device_locked(mlz_ctx* c, hipStream_t st, const uint8_t* d_base, const m
 }
 
 // ---- host-pointer plumbing: pack blocks into one device buffer, run, copy back ----
+int ensure_stream_objects(mlz_ctx* c, size_t n_events, size_t pinned_bytes);  // mlz_stream.hip.inc
+
+// Host-pointer batch: the blocks are cut into groups, and copy-in (stream s_in), kernels (the context's
+// stream) and copy-out (s_out) of different groups overlap — the PCIe crossings (63 GB/s spec each way) cost about as
+// much as the kernels, so run one after the other they halve the rate a Go caller sees.  Every copy is enqueued up
+// front; the host only waits for a group's sizes (a few bytes per block) before it enqueues that group's exact-size
+// copy-out, while the next groups' kernels are already queued.
+// Group sizes: encode is bound by the copy-in (the kernels of the last group are what is left over when it ends: small
+// groups); decode is bound by the kernels' own PCIe writes (every group drains its tail before the next starts: few groups).
+
 int host_batch(mlz_ctx* c, bool encode, int level, int n, const uint8_t* const* src, const size_t* src_len, uint8_t* const* dst, const size_t* dst_cap,
                int64_t* out_len, bool with_header, const size_t* decoded_len /* decode_block only */) {
     std::lock_guard<std::mutex> lk(c->mu);
     HIPCHK(c, hipSetDevice(c->device));
     std::vector<mlz_block_desc> desc(n);
-    size_t in_total = 0, out_total = 0;
+    std::vector<int> gstart{0};
+    size_t in_total = 0, out_total = 0, acc = 0;
     for (int i = 0; i < n; i++) {
         desc[i].src_off = in_total; desc[i].src_len = src_len[i];
         in_total += (src_len[i] + 63) & ~size_t(63);
@@ -488,24 +504,59 @@ int host_batch(mlz_ctx* c, bool encode, int level, int n, const uint8_t* const* 
         else cap = std::min<size_t>(cap, kMaxBlockSize);
         desc[i].dst_off = out_total; desc[i].dst_cap = cap;
         out_total += (cap + 63) & ~size_t(63);
+        acc += std::max<size_t>(src_len[i], cap);
+        if (acc >= (encode ? c->host_group_enc : c->host_group_dec) && i + 1 < n) { gstart.push_back(i + 1); acc = 0; }
     }
+    gstart.push_back(n);
+    const size_t ngroups = gstart.size() - 1;
+    // Pinned (page-locked, device-visible) destinations are written by the kernels themselves: the gather pass of the
+    // encoder stores the block straight into the caller's buffer and the decoder's passes store every tile there as
+    // well as in HBM, so the batch has no copy-out stage at all (on this ROCm build the copy-out ran as shader copies
+    // that queued up behind every kernel of the batch).  Pageable destinations go through the copy-out below.
+    std::vector<uint64_t> mirror(size_t(n), 0);
+    bool use_mirror = encode || (c->decode_algo == 0 && c->general_algo == 0);
+    for (int i = 0; use_mirror && i < n; i++) {
+        hipPointerAttribute_t at;
+        if (hipPointerGetAttributes(&at, dst[i]) != hipSuccess || at.type != hipMemoryTypeHost) { (void)hipGetLastError(); use_mirror = false; break; }
+        mirror[size_t(i)] = reinterpret_cast<uint64_t>(at.devicePointer ? at.devicePointer : static_cast<void*>(dst[i]));
+    }
+    const uint64_t* mir = use_mirror ? mirror.data() : nullptr;
     HIPCHK(c, c->d_in.ensure(in_total + 64));
     HIPCHK(c, c->d_out.ensure(out_total + 64));
     HIPCHK(c, c->d_len.ensure(sizeof(int64_t) * n));
-    hipStream_t st = c->stream;
-    for (int i = 0; i < n; i++)
-        if (src_len[i]) HIPCHK(c, hipMemcpyAsync(c->d_in.as<uint8_t>() + desc[i].src_off, src[i], src_len[i], hipMemcpyHostToDevice, st));
-    int r = encode ? encode_device_locked(c, st, level, c->d_in.as<uint8_t>(), c->d_out.as<uint8_t>(), desc.data(), n, c->d_len.as<int64_t>(), with_header)
-                   : decode_device_locked(c, st, c->d_in.as<uint8_t>(), c->d_out.as<uint8_t>(), desc.data(), n, c->d_len.as<int64_t>(), !with_header);
+    int r = ensure_stream_objects(c, 3 * ngroups, sizeof(int64_t) * size_t(n));
     if (r) return r;
-    HIPCHK(c, hipMemcpyAsync(out_len, c->d_len.p, sizeof(int64_t) * n, hipMemcpyDeviceToHost, st));
-    HIPCHK(c, hipStreamSynchronize(st));
-    for (int i = 0; i < n; i++) {
-        if (out_len[i] > 0) {
-            if (size_t(out_len[i]) > dst_cap[i]) { out_len[i] = -MLZ_ERR_DST_TOO_SMALL; continue; }
-            HIPCHK(c, hipMemcpyAsync(dst[i], c->d_out.as<uint8_t>() + desc[i].dst_off, size_t(out_len[i]), hipMemcpyDeviceToHost, st));
+    int64_t* h_len = static_cast<int64_t*>(c->pinned2);
+    hipStream_t st = c->stream;
+    for (size_t g = 0; g < ngroups; g++) {  // every copy-in, back to back on the copy-in stream
+        for (int i = gstart[g]; i < gstart[g + 1]; i++)
+            if (src_len[i]) HIPCHK(c, hipMemcpyAsync(c->d_in.as<uint8_t>() + desc[i].src_off, src[i], src_len[i], hipMemcpyHostToDevice, c->s_in));
+        HIPCHK(c, hipEventRecord(c->evpool[3 * g], c->s_in));
+    }
+    for (size_t g = 0; g < ngroups; g++) {  // kernels of a group once its bytes are in; its sizes go out behind them
+        const int b0 = gstart[g], cnt = gstart[g + 1] - gstart[g];
+        HIPCHK(c, hipStreamWaitEvent(st, c->evpool[3 * g], 0));
+        r = encode ? encode_device_locked(c, st, level, c->d_in.as<uint8_t>(), c->d_out.as<uint8_t>(), desc.data() + b0, cnt, c->d_len.as<int64_t>() + b0, with_header,
+                                          mir ? mir + b0 : nullptr)
+                   : decode_device_locked(c, st, c->d_in.as<uint8_t>(), c->d_out.as<uint8_t>(), desc.data() + b0, cnt, c->d_len.as<int64_t>() + b0, !with_header,
+                                          mir ? mir + b0 : nullptr);
+        if (r) { (void)hipStreamSynchronize(c->s_in); (void)hipStreamSynchronize(st); (void)hipStreamSynchronize(c->s_out); return r; }
+        HIPCHK(c, hipEventRecord(c->evpool[3 * g + 1], st));
+        HIPCHK(c, hipStreamWaitEvent(c->s_out, c->evpool[3 * g + 1], 0));
+        HIPCHK(c, hipMemcpyAsync(h_len + b0, c->d_len.as<int64_t>() + b0, sizeof(int64_t) * size_t(cnt), hipMemcpyDeviceToHost, c->s_out));
+        HIPCHK(c, hipEventRecord(c->evpool[3 * g + 2], c->s_out));
+    }
+    for (size_t g = 0; g < ngroups; g++) {  // exact-size copy-out as soon as a group's sizes are known
+        HIPCHK(c, hipEventSynchronize(c->evpool[3 * g + 2]));
+        for (int i = gstart[g]; i < gstart[g + 1]; i++) {
+            out_len[i] = h_len[i];
+            if (out_len[i] > 0) {
+                if (size_t(out_len[i]) > dst_cap[i]) { out_len[i] = -MLZ_ERR_DST_TOO_SMALL; continue; }
+                if (!use_mirror) HIPCHK(c, hipMemcpyAsync(dst[i], c->d_out.as<uint8_t>() + desc[i].dst_off, size_t(out_len[i]), hipMemcpyDeviceToHost, c->s_out));
+            }
         }
     }
+    HIPCHK(c, hipStreamSynchronize(c->s_out));
     HIPCHK(c, hipStreamSynchronize(st));
     return 0;
 }
@@ -713,6 +764,8 @@ int mlz_set_option(mlz_ctx* c, int opt, int64_t value) {
     case MLZ_OPT_DECODE_ALGO: c->decode_algo = int(value); return 0;
     case MLZ_OPT_ENCODE_FAR: c->encode_far = int(value); return 0;
     case 8: c->general_algo = int(value); return 0;  // 0 = pointer-jumping pass for general blocks (default), 1 = tile chain
+    case 10: c->host_group_enc = size_t(value > 0 ? value : 1) << 20; return 0;  // tuning: MiB per group of a host-pointer encode batch
+    case 11: c->host_group_dec = size_t(value > 0 ? value : 1) << 20; return 0;  // ... of a decode batch
     case 9: c->gen_spin_limit = value > 0 ? uint32_t(value) : 1u; return 0;  // grid-barrier patience of the general-block pass, in polls (tests)
     case 6: c->encode_algo = int(value); return 0;  // 0 = match + serialize kernels (default), 2 = the round-1 wave-per-tile kernel at LevelFastest / LevelSuperFast
     case 3: c->debug_status = int(value); return 0;  // debug: report failure sites in the error code

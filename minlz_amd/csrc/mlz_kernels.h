@@ -24,6 +24,8 @@ struct BlockInfo {
     uint32_t n_tiles;
     uint32_t first_seg;   // decode: index of this block's first token-stream segment
     uint32_t n_segs;
+    uint64_t mirror;      // host-pointer calls with pinned destinations: device-visible address of the caller's buffer, written by
+                          // the kernels themselves (encode: instead of dst; decode: in addition to it); 0 = none
 };
 
 }  // namespace mlz

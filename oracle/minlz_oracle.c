@@ -1319,19 +1319,27 @@ int mlzo_stream_decode(const uint8_t* src, size_t slen, uint8_t* dst, size_t dca
  * BenchmarkEncodeBlockParallel (benchmarks_test.go:101-107) / mz -bench (cmd/mz/compress.go:647-803).
  * ====================================================================================== */
 typedef struct {
-    const uint8_t* src; size_t n, block; int level, reps, decode;
+    const uint8_t* src; size_t n, block; int level, decode;
     uint8_t** enc; size_t* enc_len; /* per block (decode input) */
-    int tid, threads; size_t nblocks;
-    size_t out_bytes; /* per thread: compressed bytes produced (encode) */
+    size_t nblocks, items;
+    volatile size_t* next;          /* shared work counter: (rep, block) items are taken one at a time */
+    pthread_barrier_t* start;       /* released by the timing thread once every worker exists and owns its buffer */
+    size_t out_bytes;               /* per thread: compressed bytes produced (encode) */
+    double t_end;                   /* when this worker ran out of work */
 } bench_arg;
 
-/* Work items are (rep, block) pairs dealt round-robin to the threads, so every thread is busy
- * even when there are fewer blocks than cores; each thread owns its output buffer. */
+static double now_s(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
+
+/* Thread creation, buffer allocation and the first touch of the buffer happen BEFORE the clock starts; inside the
+ * timed region a worker only takes the next (rep, block) item and runs the codec on it. */
 static void* bench_worker(void* p) {
     bench_arg* a = (bench_arg*)p;
     uint8_t* tmp = (uint8_t*)malloc(a->block + 16);
-    size_t items = (size_t)a->reps * a->nblocks;
-    for (size_t it = (size_t)a->tid; it < items; it += (size_t)a->threads) {
+    memset(tmp, 0, a->block + 16);
+    pthread_barrier_wait(a->start);
+    for (;;) {
+        const size_t it = __atomic_fetch_add(a->next, 1, __ATOMIC_RELAXED);
+        if (it >= a->items) break;
         size_t b = it % a->nblocks;
         size_t off = b * a->block, bl = a->n - off < a->block ? a->n - off : a->block;
         if (!a->decode) {
@@ -1342,27 +1350,31 @@ static void* bench_worker(void* p) {
             mlzo_decode(a->enc[b], a->enc_len[b], tmp, a->block + 16, &dl);
         }
     }
+    a->t_end = now_s();
     free(tmp);
     return NULL;
 }
-
-static double now_s(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
 
 static double bench_run(const uint8_t* src, size_t n, size_t block, int level, int threads, int reps, int decode,
                         uint8_t** enc, size_t* enc_len, size_t nblocks, size_t* out_bytes) {
     pthread_t* th = (pthread_t*)malloc(sizeof(pthread_t) * threads);
     bench_arg* args = (bench_arg*)malloc(sizeof(bench_arg) * threads);
-    double t0 = now_s();
+    pthread_barrier_t start;
+    pthread_barrier_init(&start, NULL, (unsigned)threads + 1);
+    volatile size_t next = 0;
     for (int t = 0; t < threads; t++) {
-        args[t] = (bench_arg){src, n, block, level, reps, decode, enc, enc_len, t, threads, nblocks, 0};
+        args[t] = (bench_arg){src, n, block, level, decode, enc, enc_len, nblocks, (size_t)reps * nblocks, &next, &start, 0, 0.0};
         pthread_create(&th[t], NULL, bench_worker, &args[t]);
     }
+    pthread_barrier_wait(&start);   /* every worker is parked at the barrier with its buffer: start the clock */
+    const double t0 = now_s();
     size_t tot = 0;
-    for (int t = 0; t < threads; t++) { pthread_join(th[t], NULL); tot += args[t].out_bytes; }
-    double dt = now_s() - t0;
+    double t1 = t0;
+    for (int t = 0; t < threads; t++) { pthread_join(th[t], NULL); tot += args[t].out_bytes; if (args[t].t_end > t1) t1 = args[t].t_end; }
+    pthread_barrier_destroy(&start);
     if (out_bytes) *out_bytes = tot;
     free(th); free(args);
-    return dt;
+    return t1 - t0;
 }
 
 /* reps passes over the blocks of src; *total_out = compressed bytes of ONE pass. */

@@ -349,3 +349,67 @@ def test_device_calls_on_two_streams_share_the_workspace(ctx):
     out_a = b"".join(O.decode(ha[i * stride:i * stride + l].tobytes()) for i, l in enumerate(la.cpu().tolist()))
     out_b = b"".join(O.decode(hb[i * stride:i * stride + l].tobytes()) for i, l in enumerate(lb.cpu().tolist()))
     assert out_a == a.tobytes() and out_b == b_.tobytes()
+
+
+def test_host_batch_pinned_destinations(ctx):
+    # Host-pointer batch calls with page-locked buffers: the kernels write the caller's buffers themselves (no copy-out
+    # stage).  Every kind of block goes through it — tokens, stored, tiny, empty, and (decode) streams of the
+    # reference's algorithm, which take the general path — at odd offsets, with guard bytes between the blocks.
+    import ctypes as C
+    import torch
+    from minlz_amd import _lib
+    L = _lib.lib()
+    vp, sz = C.c_void_p, C.c_size_t
+    parts = [synth.text_like(8 << 20, 51), synth.enwik_like(5_000_011, 52), synth.random_bytes(1 << 20, seed=3), synth.text_like(20, 5),
+             np.zeros(0, dtype=np.uint8), synth.json_like(3 << 20, 53), synth.pattern("zeros", 70001)]
+    n = len(parts)
+    for level in (mz.LevelFastest, mz.LevelBalanced):
+        src = torch.zeros(sum(p.size for p in parts) + 64 * n, dtype=torch.uint8, pin_memory=True)
+        soff, cur = [], 3
+        for p in parts:
+            soff.append(cur); src.numpy()[cur:cur + p.size] = p; cur += p.size + 5
+        caps = [mz.MaxEncodedLen(p.size) for p in parts]
+        enc = torch.full((sum(caps) + 64 * n,), 0xA5, dtype=torch.uint8, pin_memory=True)
+        eoff, cur = [], 7
+        for c_ in caps:
+            eoff.append(cur); cur += c_ + 9
+        sp = (vp * n)(*[src.data_ptr() + o for o in soff]); sl = (sz * n)(*[p.size for p in parts])
+        ep = (vp * n)(*[enc.data_ptr() + o for o in eoff]); ec = (sz * n)(*caps)
+        ol = (C.c_int64 * n)()
+        assert L.mlz_encode_batch(ctx.handle, level, n, sp, sl, ep, ec, ol) == 0
+        eh = enc.numpy()
+        encs = []
+        for p, o, c_, l in zip(parts, eoff, caps, ol):
+            assert 0 < l <= c_
+            e = eh[o:o + l].tobytes()
+            assert O.decode(e) == p.tobytes()
+            encs.append(e)
+        keep = np.ones(eh.size, dtype=bool)
+        for o, c_ in zip(eoff, caps):
+            keep[o:o + c_] = False
+        assert (eh[keep] == 0xA5).all()                      # nothing outside the blocks' ranges was written
+        assert encs == mz.encode_batch([p.tobytes() for p in parts], level, ctx)   # same bytes as the pageable path
+    # decode: this library's blocks and the reference algorithm's (general path), into pinned memory
+    blobs = encs + [O.encode(parts[0], 1), O.encode(parts[5], 2)]
+    outs = parts + [parts[0], parts[5]]
+    m = len(blobs)
+    cbuf = torch.zeros(sum(len(b) for b in blobs) + 16 * m, dtype=torch.uint8, pin_memory=True)
+    coff, cur = [], 1
+    for b in blobs:
+        coff.append(cur); cbuf.numpy()[cur:cur + len(b)] = np.frombuffer(b, dtype=np.uint8); cur += len(b) + 3
+    dec = torch.full((sum(p.size for p in outs) + 64 * m,), 0x5A, dtype=torch.uint8, pin_memory=True)
+    doff, cur = [], 5
+    for p in outs:
+        doff.append(cur); cur += p.size + 11
+    cp = (vp * m)(*[cbuf.data_ptr() + o for o in coff]); cl = (sz * m)(*[len(b) for b in blobs])
+    dp = (vp * m)(*[dec.data_ptr() + o for o in doff]); dc = (sz * m)(*[p.size for p in outs])
+    dl = (C.c_int64 * m)()
+    assert L.mlz_decode_batch(ctx.handle, m, cp, cl, dp, dc, dl) == 0
+    dh = dec.numpy()
+    keep = np.ones(dh.size, dtype=bool)
+    for p, o, l in zip(outs, doff, dl):
+        assert l == p.size
+        assert dh[o:o + l].tobytes() == p.tobytes()
+        keep[o:o + p.size] = False
+    assert (dh[keep] == 0x5A).all()
+    assert ctx.general_blocks() == 2

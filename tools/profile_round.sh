@@ -3,7 +3,7 @@
 # HBM-side traffic per kernel, and the bench line.  usage: profile_round.sh <tag>
 R=$GRAFT_REPO_ROOT; tag=$1
 cd /tmp && export TMPDIR=/tmp
-timeout 300 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_$tag -o t -- python $R/bench.py --steps 10 --warmup 2 --no-cpu > $R/gpurun_out/prof_$tag.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_$tag -o t -- python $R/bench.py --steps 10 --warmup 2 --no-cpu --no-extras > $R/gpurun_out/prof_$tag.log 2>&1
 python $R/tools/rocpd_summary.py $R/gpurun_out/prof_$tag/t_results.db > $R/gpurun_out/${tag}_kernel_stats.txt
 bash $R/tools/pmc_run.sh
 python $R/tools/rocpd_pmc.py $R/gpurun_out/pmc_1/p1_results.db $R/gpurun_out/pmc_4/p4_results.db > $R/gpurun_out/${tag}_pmc_counters.txt 2>&1

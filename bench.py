@@ -112,6 +112,64 @@ def cpu_baseline(host, budget_s=20.0):
                              else "not timed: `go` is not installed on this box (probed at run time)"}
 
 
+def stream_mode(args, ctx, mz, synth, dist, dev, rank, world):
+    """BASELINE config 3: one stream (JSON-like by default use --workload json --level 2), blocks in contiguous ranges over the
+    ranks, every range encoded + framed on its GPU, runs gathered in order into rank 0's HBM.  Strong scaling: --bytes is the
+    whole stream.  Rank 0 prints one JSON line with per-rank kernel times and the time spent outside the kernels."""
+    from minlz_amd import shard
+    total = args.bytes
+    n_blocks = (total + BLOCK - 1) // BLOCK
+    b0, b1 = shard.range_of(rank, world, n_blocks)
+    lo, hi = min(b0 * BLOCK, total), min(b1 * BLOCK, total)
+    gen = {"enwik": synth.enwik_like, "text": synth.text_like, "json": synth.json_like, "random": synth.random_bytes}[args.workload]
+    host = gen(max(hi - lo, 1), seed=100 + rank)[:hi - lo]     # every rank generates only its own range
+    src = torch.from_numpy(host).to(dev)
+    codec = shard.HipTensorCodec(ctx)
+
+    def step():
+        return shard.encode_stream_sharded_device(codec, src, total, BLOCK, args.level, rank, world)
+    out = step()
+    torch.cuda.synchronize(dev)
+    clen = int(out.numel()) if out is not None else 0
+    if rank == 0 and world == 1:       # whole stream on this rank: check it (the N > 1 layout is covered by tests/test_dist_gloo.py)
+        assert mz.stream_decode(out.cpu().numpy().tobytes(), ctx=ctx) == host.tobytes()
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize(dev)
+    ctx.set_option(mz.OPT_TIMING, 2)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize(dev)
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    kern = dict(ctx.timers())
+    ctx.set_option(mz.OPT_TIMING, 0)
+    k_ms = sum(v for k, v in kern.items() if k.startswith("enc_") or k == "crc")
+    per_rank = [k_ms]
+    if dist is not None:
+        tt = torch.tensor([elapsed, k_ms], dtype=torch.float64, device=dev)
+        allt = [torch.zeros_like(tt) for _ in range(world)]
+        dist.all_gather(allt, tt)
+        elapsed = max(float(t[0]) for t in allt)
+        per_rank = [round(float(t[1]), 4) for t in allt]
+    if rank == 0:
+        ms = elapsed / args.steps * 1e3
+        print(json.dumps({"metric": "MB/s stream encode, 8MB blocks, one stream over N GPUs", "value": round(total / 1e6 / (elapsed / args.steps), 1), "unit": "MB/s",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 4), "higher_is_better": True,
+                          "scaling": "strong", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+                          "config": {"workload": "%s stream of %d B in 8 MiB blocks, level %d, contiguous block ranges per rank, framed chunks (CRC32C on the device) "
+                                                 "gathered in order into rank 0's HBM" % (args.workload, total, args.level),
+                                     "stream_bytes": clen, "ratio": round(clen / max(total, 1), 4), "kernel_ms_per_rank": per_rank,
+                                     "outside_kernels_ms": round(ms - max(per_rank), 4), "device": ctx.device_name()}}), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -124,15 +182,21 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-extras", action="store_true", help="skip the foreign-stream, end-to-end and round-1 stand-in legs")
     ap.add_argument("--workload", default="enwik", choices=["enwik", "text", "json", "random"])
+    ap.add_argument("--mode", default="blocks", choices=["blocks", "stream"],
+                    help="blocks (default, the BASELINE metric): every rank encodes + decodes its own blocks, the compressed payload is gathered to rank 0; "
+                         "stream (BASELINE config 3): ONE stream of --bytes total cut into contiguous block ranges over the ranks, framed and gathered "
+                         "into rank 0's HBM (minlz_amd/shard.py), strong scaling")
     ap.add_argument("--file", default=os.environ.get("MINLZ_BENCH_FILE"), help="real input (e.g. enwik8); every rank reads its own --bytes slice, wrapping around")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    if world > 1 or os.environ.get("MINLZ_BENCH_FORCE_DIST"):   # (the env switch runs the N > 1 code path with one rank: a smoke test)
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         torch.cuda.set_device(local)
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
     else:
@@ -149,6 +213,9 @@ def main():
     ctx.set_option(mz.OPT_ENCODE_FAR, args.far)
     if args.algo >= 0:
         ctx.set_option(6, args.algo)
+
+    if args.mode == "stream":
+        return stream_mode(args, ctx, mz, synth, dist, dev, rank, world)
 
     # ---- the stream of this rank (weak scaling: every rank has its own S bytes) ----
     S = args.bytes
@@ -224,6 +291,8 @@ def main():
             t0 = time.perf_counter()
             for _ in range(steps):
                 step()
+            if collective is not None and hasattr(collective, "drain"):
+                collective.drain()
             torch.cuda.synchronize(dev)
             if dist is not None:
                 dist.barrier()
@@ -237,14 +306,43 @@ def main():
     main_leg.check()                       # correctness outside the timed region
     C_total = sum(main_leg.clens)
 
-    gathered = [torch.empty_like(main_leg.enc_len) for _ in range(world)] if dist is not None else None
+    gather_info = None
+    if dist is not None:
+        from minlz_amd import shard
+        n_all = nblk * world
+        pending = []
 
-    def collective(enc_len):
-        # the stream writer's only exchange when every rank writes its own part: every rank learns every block's compressed size
-        # (output offsets / index, writer.go:223-243) — an RCCL all_gather of nblk int64
-        dist.all_gather(gathered, enc_len)
+        def collective(enc_len):
+            # The Writer's exchange (writer.go:219-272): every rank learns every block's compressed size (an RCCL all_gather of
+            # nblk int64) and the compressed blocks travel, in stream order, into rank 0's HBM — isend / irecv of one compact
+            # run per rank over xGMI, posted here and overlapped with this rank's decode (which reads its own copy).
+            while pending:
+                shard.finish_gather(pending.pop())
+            sizes = shard.gather_chunk_sizes(enc_len.cpu().tolist(), n_all, rank, world, dev)
+            mine = sizes[rank * nblk:(rank + 1) * nblk]
+            run = torch.empty(max(sum(mine), 1), dtype=torch.uint8, device=dev)
+            o = 0
+            for i, l in enumerate(mine):
+                run[o:o + l] = main_leg.enc[i * main_leg.stride:i * main_leg.stride + l]
+                o += l
+            out, works, payload = shard.start_gather(run, sizes, n_all, rank, world, 0)
+            pending.append(works)
+            collective.keep = (run, out)          # alive until the transfers are done
+            collective.payload = payload
 
-    elapsed, kavg = main_leg.timed(args.steps, args.warmup, collective if dist is not None else None)
+        def drain():                              # the last step's transfers belong to the timed region
+            while pending:
+                shard.finish_gather(pending.pop())
+        collective.drain = drain
+    else:
+        collective = None
+
+    elapsed, kavg = main_leg.timed(args.steps, args.warmup, collective)
+    if dist is not None:
+        while pending:
+            shard.finish_gather(pending.pop())
+        torch.cuda.synchronize(dev)
+        gather_info = {"root": 0, "payload_bytes_per_step": int(collective.payload), "transport": "isend/irecv of one compact run per rank into rank 0's HBM, overlapped with decode"}
     if dist is not None:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -362,6 +460,8 @@ def main():
            "hbm_read_frac_north_star": round((S / 1e9 / ((enc_ms + dec_ms) / 1e3)) / HBM_PEAK_GBS, 5) if enc_ms + dec_ms else None,
            "device": ctx.device_name()}
     cfg.update(extras)
+    if gather_info:
+        cfg["gather"] = gather_info
     out = {
         "metric": "MB/s encode+decode, 8MB blocks L1",
         "value": round(value, 1),

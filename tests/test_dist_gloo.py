@@ -30,6 +30,21 @@ def _worker(rank, world, port, q):
         mine = shard.my_blocks(n_blocks, rank, world)
         sizes = shard.gather_sizes([100 + b for b in mine], n_blocks, rank, world)
         results.append(sizes == [100 + b for b in range(n_blocks)])
+        # device-resident path (CPU tensors here): contiguous block ranges, chunk runs framed per rank, payload gather with
+        # isend / irecv into the root's buffer at the final offsets; byte-identical to the reference-shaped stream
+        import torch
+        codec = shard.OracleTensorCodec()
+        for data, bs in ((synth.text_like(700001, 5).tobytes(), 65536), (synth.random_bytes(300000).tobytes(), 65536), (b"", 4096),
+                         (synth.text_like(5000, 6).tobytes(), 4096), (synth.json_like(2_500_000).tobytes(), 1 << 20)):
+            n_blocks = (len(data) + bs - 1) // bs
+            b0, b1 = shard.range_of(rank, world, n_blocks)
+            lo, hi = min(b0 * bs, len(data)), min(b1 * bs, len(data))
+            src = torch.frombuffer(bytearray(data[lo:hi]), dtype=torch.uint8) if hi > lo else torch.zeros(0, dtype=torch.uint8)
+            out = shard.encode_stream_sharded_device(codec, src, len(data), bs, 1, rank, world)
+            if rank == 0:
+                sb = out.numpy().tobytes()
+                results.append(sb == O.stream_encode(data, 1, bs) and O.stream_decode(sb, len(data)) == data)
+        results.append(shard.range_of(0, 3, 7) == (0, 3) and shard.range_of(1, 3, 7) == (3, 5) and shard.range_of(2, 3, 7) == (5, 7))
         if rank == 0:
             q.put(results)
     finally:

@@ -70,6 +70,7 @@ struct Params {
     int far_stride2;  // experiment: far probes only at even positions
     int lazy_local;   // 1: the look-ahead does not cross a 64-position window
     int far_hash24;   // 1: far hash from 24-bit multiply-adds
+    int far_prev;     // 1: the previous epoch's table is probed as well (LevelBalanced)
 };
 
 struct Rec { uint32_t mp, len, off; };
@@ -167,7 +168,9 @@ size_t model2_block(const uint8_t* src, size_t n, const Params* P, uint8_t* out,
                         if (b > maxl) b = maxl;
                         if (use_far && !(P->far_gate && b >= 8) && !(P->far_stride2 && (p & 1))) {
                             const FarHash fh = far_hash(v, kFarBits);
-                            const size_t ep = (base + p) >> kEpochLog;
+                            const size_t ep0 = (base + p) >> kEpochLog;
+                            for (int kk = 0; kk <= (P->far_prev && ep0 > 0 ? 1 : 0); kk++) {
+                            const size_t ep = ep0 - size_t(kk);
                             const uint32_t en = ftab[(ep << kFarBits) + fh.idx];
                             if ((en & kFarTagMask) == fh.tag) {
                                 const uint32_t fq = en >> kFarTagBits;
@@ -183,6 +186,7 @@ size_t model2_block(const uint8_t* src, size_t n, const Params* P, uint8_t* out,
                                         if (k >= uint32_t(P->min_far) && k > b + 2) { b = k; bo = off; }
                                     }
                                 }
+                            }
                             }
                         }
                         if (b < 4) b = 0;

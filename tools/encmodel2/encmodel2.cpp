@@ -71,6 +71,7 @@ struct Params {
     int lazy_local;   // 1: the look-ahead does not cross a 64-position window
     int far_hash24;   // 1: far hash from 24-bit multiply-adds
     int far_prev;     // 1: the previous epoch's table is probed as well (LevelBalanced)
+    unsigned pattern; // != 0: level pattern override (2 bits per tile, period 16)
 };
 
 struct Rec { uint32_t mp, len, off; };
@@ -81,7 +82,7 @@ extern "C" {
 // stats[0] = tokens, [1] = literal bytes, [2] = far tokens, [3] = repeat tokens, [4] = windows probed
 size_t model2_block(const uint8_t* src, size_t n, const Params* P, uint8_t* out, uint64_t* stats) {
     g_hash24 = P->far_hash24;
-    const uint32_t pat = P->dense ? kPatternDense : kPatternFast;
+    const uint32_t pat = P->pattern ? P->pattern : P->dense ? kPatternDense : kPatternFast;
     const size_t ntiles = (n + kTile - 1) >> kTileLog;
     const size_t nepoch = (n + (size_t(1) << kEpochLog) - 1) >> kEpochLog;
     std::vector<uint32_t> far_tab;

@@ -283,10 +283,11 @@ int encode_device_locked(mlz_ctx* c, hipStream_t st, int level, const uint8_t* d
             HIPCHK(c, c->d_piece_cnt.ensure(units * sizeof(uint32_t)));
             {
                 Timer t(c, T_ENC_TILES, st);
-                if (far) hipLaunchKernelGGL((match_tiles_kernel<true, MLZ_M2_NW>), dim3(tiles), dim3(256), kM2Lds, st, d_src, blocks, tile_block,
-                                            c->d_recs.as<uint2>(), c->d_piece_cnt.as<uint32_t>(), ftab, epochs, pattern);
-                else hipLaunchKernelGGL((match_tiles_kernel<false, MLZ_M2_NW>), dim3(tiles), dim3(256), kM2Lds, st, d_src, blocks, tile_block,
-                                        c->d_recs.as<uint2>(), c->d_piece_cnt.as<uint32_t>(), ftab, epochs, pattern);
+                const uint32_t grid = ((tiles + 7) / 8) * 8;  // whole rounds of the eight XCDs (see the kernel's workgroup -> tile map)
+                if (far) hipLaunchKernelGGL((match_tiles_kernel<true, MLZ_M2_NW>), dim3(grid), dim3(256), kM2Lds, st, d_src, blocks, tile_block,
+                                            c->d_recs.as<uint2>(), c->d_piece_cnt.as<uint32_t>(), ftab, epochs, pattern, tiles);
+                else hipLaunchKernelGGL((match_tiles_kernel<false, MLZ_M2_NW>), dim3(grid), dim3(256), kM2Lds, st, d_src, blocks, tile_block,
+                                        c->d_recs.as<uint2>(), c->d_piece_cnt.as<uint32_t>(), ftab, epochs, pattern, tiles);
             }
             {
                 Timer t(c, T_ENC_SER, st);

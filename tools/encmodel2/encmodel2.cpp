@@ -72,6 +72,7 @@ struct Params {
     int far_hash24;   // 1: far hash from 24-bit multiply-adds
     int far_prev;     // 1: the previous epoch's table is probed as well (LevelBalanced)
     unsigned pattern; // != 0: level pattern override (2 bits per tile, period 16)
+    int graded;       // 1: piece k of a tile has (k+1)/sub of the near-table entries (same positions-per-entry for every piece)
 };
 
 struct Rec { uint32_t mp, len, off; };
@@ -115,10 +116,12 @@ size_t model2_block(const uint8_t* src, size_t n, const Params* P, uint8_t* out,
             const uint32_t pe = ps + piece_len < tl ? ps + piece_len : tl;
             recs.clear();
             std::fill(table.begin(), table.end(), uint16_t(0));
+            const uint32_t tsize = P->graded ? uint32_t(((ps / piece_len) + 1) * (table.size() / size_t(P->sub))) : uint32_t(table.size());
+            auto tix = [&](uint32_t h) -> uint32_t { return uint32_t((uint64_t(h) * tsize) >> P->near_bits); };
             if (P->seed)
                 for (uint32_t p = 0; p < ps; p++) {
                     const uint32_t h1 = hash4(ld64z(s, p, tl), P->near_bits + 1);
-                    table[h1 >> 1] = uint16_t(p | ((h1 & 1) << 15));
+                    table[tix(h1 >> 1)] = uint16_t(p | ((h1 & 1) << 15));
                 }
             uint32_t cur = ps, pos = ps, rep = 0;
             // the kernel's far pipeline: candidates exist for an iteration only if its windows were the expected ones
@@ -139,7 +142,7 @@ size_t model2_block(const uint8_t* src, size_t n, const Params* P, uint8_t* out,
                         const uint32_t p = cur + w * W + l;
                         valid[w * W + l] = p + 4 <= pe;
                         const uint32_t h1 = hash4(ld64z(s, p, tl), P->near_bits + 1);
-                        hh[l] = h1 >> 1; tg[l] = (h1 & 1) << 15;
+                        hh[l] = tix(h1 >> 1); tg[l] = (h1 & 1) << 15;
                         e[l] = table[hh[l]];
                     }
                     for (int l = 0; l < W; l++) if (valid[w * W + l]) table[hh[l]] = uint16_t((cur + w * W + l) | tg[l]);

@@ -262,8 +262,9 @@ int encode_device_locked(mlz_ctx* c, hipStream_t st, int level, const uint8_t* d
         const bool far = ((c->encode_far && level != MLZ_LEVEL_SUPERFAST) || level == MLZ_LEVEL_BALANCED) && maxlen > kTile;
         const uint32_t pattern = level_pattern_of(level == MLZ_LEVEL_BALANCED ? 2 : 1);
         if (!c->enc_attrs) {  // per context = per device
-            HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(match_tiles_kernel<true, MLZ_M2_NW>), hipFuncAttributeMaxDynamicSharedMemorySize, kM2Lds));
-            HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(match_tiles_kernel<false, MLZ_M2_NW>), hipFuncAttributeMaxDynamicSharedMemorySize, kM2Lds));
+            HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(match_tiles_kernel<true, MLZ_M2_NW, kM2HashBitsFast>), hipFuncAttributeMaxDynamicSharedMemorySize, M2Cfg<kM2HashBitsFast>::kLds));
+            HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(match_tiles_kernel<false, MLZ_M2_NW, kM2HashBitsFast>), hipFuncAttributeMaxDynamicSharedMemorySize, M2Cfg<kM2HashBitsFast>::kLds));
+            HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(match_tiles_kernel<false, MLZ_M2_NW, kM2HashBitsSuperFast>), hipFuncAttributeMaxDynamicSharedMemorySize, M2Cfg<kM2HashBitsSuperFast>::kLds));
             c->enc_attrs = true;
         }
         if (far) {
@@ -284,10 +285,13 @@ int encode_device_locked(mlz_ctx* c, hipStream_t st, int level, const uint8_t* d
             {
                 Timer t(c, T_ENC_TILES, st);
                 const uint32_t grid = ((tiles + 7) / 8) * 8;  // whole rounds of the eight XCDs (see the kernel's workgroup -> tile map)
-                if (far) hipLaunchKernelGGL((match_tiles_kernel<true, MLZ_M2_NW>), dim3(grid), dim3(256), kM2Lds, st, d_src, blocks, tile_block,
-                                            c->d_recs.as<uint2>(), c->d_piece_cnt.as<uint32_t>(), ftab, epochs, pattern, tiles);
-                else hipLaunchKernelGGL((match_tiles_kernel<false, MLZ_M2_NW>), dim3(grid), dim3(256), kM2Lds, st, d_src, blocks, tile_block,
-                                        c->d_recs.as<uint2>(), c->d_piece_cnt.as<uint32_t>(), ftab, epochs, pattern, tiles);
+#define MLZ_LAUNCH_M2(F, HB)                                                                                                                 \
+    hipLaunchKernelGGL((match_tiles_kernel<F, MLZ_M2_NW, HB>), dim3(grid), dim3(256), M2Cfg<HB>::kLds, st, d_src, blocks, tile_block,        \
+                       c->d_recs.as<uint2>(), c->d_piece_cnt.as<uint32_t>(), ftab, epochs, pattern, tiles)
+                if (level == MLZ_LEVEL_SUPERFAST) MLZ_LAUNCH_M2(false, kM2HashBitsSuperFast);
+                else if (far) MLZ_LAUNCH_M2(true, kM2HashBitsFast);
+                else MLZ_LAUNCH_M2(false, kM2HashBitsFast);
+#undef MLZ_LAUNCH_M2
             }
             {
                 Timer t(c, T_ENC_SER, st);

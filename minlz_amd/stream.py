@@ -177,7 +177,7 @@ class Reader:
         """Decode the queued chunks in one batch and append the results in stream order."""
         if not pending:
             return
-        comp = [(i, p) for i, p in enumerate(pending) if p[0] == "c"]
+        comp = [(i, p) for i, p in enumerate(pending) if p[0] in ("c", "c3")]
         decoded = self.backend.decode_bodies([p[1] for _, p in comp]) if comp else []
         res = [None] * len(pending)
         for (i, _), d in zip(comp, decoded):
@@ -186,7 +186,7 @@ class Reader:
             if p[0] == "u":
                 res[i] = p[1]
         if not self.ignore_crc:
-            crcs = self.backend.crcs(res)
+            crcs = self.backend.crcs([p[3] if p[0] == "c3" else d for p, d in zip(pending, res)])   # 0x03: CRC of the token bytes
             for p, c in zip(pending, crcs):
                 if c != p[2]:
                     raise api.ErrCRC()
@@ -224,9 +224,8 @@ class Reader:
                 body_len = clen - 4 - hl
                 if n == 0 or n < body_len:
                     raise api.ErrCorrupt()  # reader.go:327
-                if ctype == CHUNK_MINLZ_COMPCRC:
-                    raise api.ErrUnsupported("chunk 0x03 (CRC over compressed bytes)")
-                pending.append(("c", buf[4:], crc))
+                # type 0x03: the CRC covers the token bytes instead of the decoded ones (reader.go:341-344)
+                pending.append(("c3" if ctype == CHUNK_MINLZ_COMPCRC else "c", buf[4:], crc, buf[4 + hl:]))
                 stream_out += n
             elif ctype == CHUNK_UNCOMPRESSED:
                 if clen < 4 or clen > api.MaxEncodedLen(max_block) + 4:

@@ -118,3 +118,36 @@ def test_stream_abi_errors(ctx):
     # framing KAT (minlz_test.go:1120-1134)
     kat = bytes.fromhex("ff0600004d696e4c7a02") + b"\x01\x08\x00\x00" + b"\x68\x10\xe6\xb6" + b"abcd" + b"\x20\x00\x00\x00"
     assert mz.stream_decode(kat, ctx=ctx) == b"abcd"
+
+
+def _to_compcrc(stream):
+    """Rewrite every 0x02 chunk as 0x03 (same body; the CRC covers the token bytes, SPEC chunk 0x03 / reader.go:341-344)."""
+    from minlz_amd.stream import uvarint
+    b = bytearray(stream)
+    p = 0
+    while p + 4 <= len(b):
+        t = b[p]
+        n = b[p + 1] | b[p + 2] << 8 | b[p + 3] << 16
+        if t == 0x02:
+            _, hl = uvarint(b, p + 8)
+            b[p] = 0x03
+            b[p + 4:p + 8] = O.crc(bytes(b[p + 8 + hl:p + 4 + n])).to_bytes(4, "little")
+        p += 4 + n
+    return bytes(b)
+
+
+def test_chunk_type_3_crc_over_compressed_bytes(ctx):
+    # chunk 0x03 = MinLZ block whose CRC is taken over the compressed bytes (the reference's LZ4 converter writes these,
+    # lz4convert.go:412; its Reader accepts them everywhere a 0x02 chunk may stand)
+    d = synth.text_like(3_000_000, 61).tobytes() + synth.random_bytes(100_000).tobytes() + synth.json_like(500_000).tobytes()
+    s2 = mz.stream_encode(d, 1, 1 << 20, ctx=ctx)
+    s3 = _to_compcrc(s2)
+    assert s3 != s2 and O.stream_decode(s3, len(d)) == d            # the reference-shaped reader takes it
+    assert mz.stream_decode(s3, ctx=ctx) == d                       # mlz_stream_decode
+    out = io.BytesIO()
+    S.Reader(io.BytesIO(s3), backend=S.HipBackend(ctx)).WriteTo(out)   # the incremental mirror
+    assert out.getvalue() == d
+    bad = bytearray(s3)
+    bad[len(bad) // 2] ^= 0x40
+    with pytest.raises(mz.MinLZError):
+        mz.stream_decode(bytes(bad), ctx=ctx)

@@ -104,6 +104,7 @@ class Writer:
         blocks = [data[i:i + bs] for i in range(0, take, bs)]
         if not self.wrote_header:  # header goes out with the first block (writer.go:463-467)
             self.wrote_header = True
+            self.index.add(0, 0)  # the header's own entry (writer.go:236-243); it makes index.add drop the first block's (10, 0)
             self._emit(MAGIC + bytes([(bs - 1).bit_length() - 10]))
         for g in range(0, len(blocks), self.batch):
             grp = blocks[g:g + self.batch]

@@ -1039,6 +1039,10 @@ long mlzo_stream_encode_ex(uint8_t* dst, size_t dcap, const uint8_t* src, size_t
         memcpy(dst, MAGIC_CHUNK, 9); dst[9] = (uint8_t)(bits_len(block_size - 1) - 10); o = 10;
     }
     size_t pos = 0;
+    /* The default (concurrent) Writer hands the stream header to its output goroutine like a block, and that goroutine
+     * calls index.add(w.written = 0, startOffset = 0) for it (writer.go:236-243); the first block's add(10, 0) is then
+     * dropped by index.add's distance rule (index.go:87-90).  The index therefore starts at (0, 0). */
+    if (add_index && n > 0) { ic[nb] = 0; iu[nb] = 0; nb++; }
     while (pos < n) {
         size_t bl = n - pos < block_size ? n - pos : block_size;
         const uint8_t* u = src + pos;

@@ -75,8 +75,10 @@ def test_index_bytes_three_ways(bs):
     assert (tu, tc, est, offs) == (ix.total_uncompressed, ix.total_compressed, ix.est_block_uncomp, ix.offsets)
     assert spec_decode(chunk) == (tu, tc, est, offs)
     assert tu == len(d) and tc == len(plain)
-    # every entry points at a chunk header of a data block and at the right uncompressed offset
-    for c, u in offs:
+    # the first entry is the stream header's own (0, 0) — the default Writer's output goroutine adds it (writer.go:236-243) —
+    # every other entry points at a chunk header of a data block and at the right uncompressed offset
+    assert offs[0] == (0, 0) and plain[0] == 0xff
+    for c, u in offs[1:]:
         assert plain[c] in (0x01, 0x02) and u % bs == 0
     # entries are at least 1 MiB (or one block) apart (index.go:31,56-68,80-90)
     assert all(b[1] - a[1] >= max(bs, 1 << 20) for a, b in zip(offs, offs[1:]))

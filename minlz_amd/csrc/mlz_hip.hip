@@ -84,8 +84,14 @@ struct mlz_ctx {
     std::string dev_name;
     hipStream_t stream = nullptr;  // used by the host-pointer calls
     // descriptors
-    DevBuf d_blocks, d_tile_block, d_seg_block;
-    std::vector<BlockInfo> h_blocks, h_blocks_prev;
+    // Block descriptors on the device, one set per kind of call (0 encode / crc, 1 decode): an encode and a decode that
+    // alternate (a Writer next to a Reader, bench.py) each find their descriptors already uploaded.
+    DevBuf d_blocks_k[2], d_tile_block_k[2], d_seg_block_k[2];
+    std::vector<BlockInfo> h_blocks, h_blocks_prev_k[2];
+    int dk = 0;  // kind of the call in progress
+    DevBuf& d_blocks_cur() { return d_blocks_k[dk]; }
+    DevBuf& d_tile_block_cur() { return d_tile_block_k[dk]; }
+    DevBuf& d_seg_block_cur() { return d_seg_block_k[dk]; }
     std::vector<uint32_t> h_tile_block, h_seg_block;
     void* pinned = nullptr;
     size_t pinned_cap = 0;
@@ -117,6 +123,7 @@ struct mlz_ctx {
     int encode_far = 1;
     int encode_algo = 0;  // 0 = match + serialize kernels (mlz_encode2.hip.inc), 2 = the round-1 wave-per-tile kernel (always used by LevelBalanced)
     bool enc_attrs = false, far_attr = false, dec_attrs = false, gen_attr = false;  // per device: dynamic-LDS limits raised
+    uint32_t timer_mask = 0xffffffffu;  // timers that record events (an event pair costs ~10 us of idle device per kernel boundary)
     int timing = 0;  // 0 off, 1 = the last call's kernel times, 2 = running mean over the calls since it was enabled (no sync per call)
     int debug_status = 0;
     bool prof_on = false;
@@ -150,7 +157,9 @@ namespace {
 
 struct Timer {
     mlz_ctx* c; int id; hipStream_t s;
-    Timer(mlz_ctx* c_, int id_, hipStream_t s_) : c(c_), id(id_), s(s_) {
+    bool on;
+    Timer(mlz_ctx* c_, int id_, hipStream_t s_) : c(c_), id(id_), s(s_), on(((c_->timer_mask >> id_) & 1) != 0) {
+        if (!on) return;
         if (c->timing == 1) { (void)hipEventRecord(c->ev[id][0], s); }
         else if (c->timing == 2) {
             while (c->ev_cnt[id] - c->ev_res[id] >= uint64_t(mlz_ctx::kTimerRing)) c->resolve_one(id);
@@ -158,6 +167,7 @@ struct Timer {
         }
     }
     ~Timer() {
+        if (!on) return;
         if (c->timing == 1) { (void)hipEventRecord(c->ev[id][1], s); c->ev_used[id] = true; }
         else if (c->timing == 2) { (void)hipEventRecord(c->evr[id][c->ev_cnt[id] % mlz_ctx::kTimerRing][1], s); c->ev_cnt[id]++; }
     }
@@ -179,6 +189,8 @@ struct WorkspaceOrder {
 // Builds BlockInfo / tile map on the host and uploads them when they differ from the last call.
 int upload_blocks(mlz_ctx* c, hipStream_t st, const mlz_block_desc* desc, int n, bool tiles_from_dst, uint32_t* total_tiles, uint32_t* total_segs = nullptr,
                   const uint64_t* mirror = nullptr) {
+    c->dk = tiles_from_dst ? 1 : 0;
+    std::vector<BlockInfo>& prev = c->h_blocks_prev_k[c->dk];
     c->h_blocks.resize(n);
     uint32_t tiles = 0, segs = 0;
     for (int i = 0; i < n; i++) {
@@ -201,8 +213,7 @@ int upload_blocks(mlz_ctx* c, hipStream_t st, const mlz_block_desc* desc, int n,
     }
     *total_tiles = tiles;
     if (total_segs) *total_segs = segs;
-    const bool same = c->h_blocks_prev.size() == c->h_blocks.size() &&
-                      std::memcmp(c->h_blocks_prev.data(), c->h_blocks.data(), sizeof(BlockInfo) * n) == 0;
+    const bool same = prev.size() == c->h_blocks.size() && std::memcmp(prev.data(), c->h_blocks.data(), sizeof(BlockInfo) * n) == 0;
     if (same) return 0;
     c->h_tile_block.resize(tiles);
     c->h_seg_block.resize(segs);
@@ -218,18 +229,18 @@ int upload_blocks(mlz_ctx* c, hipStream_t st, const mlz_block_desc* desc, int n,
         c->pinned_cap = (nb + nt + ns) * 2 + 4096;
         HIPCHK(c, hipHostMalloc(&c->pinned, c->pinned_cap, hipHostMallocDefault));
     }
-    HIPCHK(c, c->d_blocks.ensure(nb + 64));
-    HIPCHK(c, c->d_tile_block.ensure(nt + 64));
-    HIPCHK(c, c->d_seg_block.ensure(ns + 64));
+    HIPCHK(c, c->d_blocks_cur().ensure(nb + 64));
+    HIPCHK(c, c->d_tile_block_cur().ensure(nt + 64));
+    HIPCHK(c, c->d_seg_block_cur().ensure(ns + 64));
     std::memcpy(c->pinned, c->h_blocks.data(), nb);
     std::memcpy(static_cast<char*>(c->pinned) + nb, c->h_tile_block.data(), nt);
     std::memcpy(static_cast<char*>(c->pinned) + nb + nt, c->h_seg_block.data(), ns);
-    if (nb) HIPCHK(c, hipMemcpyAsync(c->d_blocks.p, c->pinned, nb, hipMemcpyHostToDevice, st));
-    if (nt) HIPCHK(c, hipMemcpyAsync(c->d_tile_block.p, static_cast<char*>(c->pinned) + nb, nt, hipMemcpyHostToDevice, st));
-    if (ns) HIPCHK(c, hipMemcpyAsync(c->d_seg_block.p, static_cast<char*>(c->pinned) + nb + nt, ns, hipMemcpyHostToDevice, st));
+    if (nb) HIPCHK(c, hipMemcpyAsync(c->d_blocks_cur().p, c->pinned, nb, hipMemcpyHostToDevice, st));
+    if (nt) HIPCHK(c, hipMemcpyAsync(c->d_tile_block_cur().p, static_cast<char*>(c->pinned) + nb, nt, hipMemcpyHostToDevice, st));
+    if (ns) HIPCHK(c, hipMemcpyAsync(c->d_seg_block_cur().p, static_cast<char*>(c->pinned) + nb + nt, ns, hipMemcpyHostToDevice, st));
     HIPCHK(c, hipEventRecord(c->upload_done, st));
     c->upload_pending = true;
-    c->h_blocks_prev = c->h_blocks;
+    prev = c->h_blocks;
     return 0;
 }
 
@@ -250,8 +261,8 @@ int encode_device_locked(mlz_ctx* c, hipStream_t st, int level, const uint8_t* d
     HIPCHK(c, c->d_tile_size.ensure(sizeof(uint32_t) * (units + 1)));
     HIPCHK(c, c->d_tile_out.ensure(sizeof(uint32_t) * (units + 1)));
     HIPCHK(c, c->d_flags.ensure(sizeof(uint32_t) * n));
-    const BlockInfo* blocks = c->d_blocks.as<BlockInfo>();
-    const uint32_t* tile_block = c->d_tile_block.as<uint32_t>();
+    const BlockInfo* blocks = c->d_blocks_cur().as<BlockInfo>();
+    const uint32_t* tile_block = c->d_tile_block_cur().as<uint32_t>();
     if (level != MLZ_LEVEL_UNCOMPRESSED && tiles > 0) {
         HIPCHK(c, c->d_scratch.ensure(v2 ? units * kPieceScratch : size_t(tiles) * kTileScratch));
         uint64_t maxlen = 0;
@@ -376,9 +387,9 @@ int decode_parallel(mlz_ctx* c, hipStream_t st, const uint8_t* d_src, uint8_t* d
     const size_t idx_bytes = (size_t(tiles) << kTileLog) * 4;
     const bool jump = c->general_algo == 0 && c->decode_algo == 0 && tiles > 0 && idx_bytes <= (size_t(4) << 30);
     if (jump) HIPCHK(c, c->d_idx.ensure(idx_bytes + size_t(tiles) * 128));  // + phase J's "all literal" flags, 128 per tile
-    const BlockInfo* blocks = c->d_blocks.as<BlockInfo>();
-    const uint32_t* tile_block = c->d_tile_block.as<uint32_t>();
-    const uint32_t* seg_block = c->d_seg_block.as<uint32_t>();
+    const BlockInfo* blocks = c->d_blocks_cur().as<BlockInfo>();
+    const uint32_t* tile_block = c->d_tile_block_cur().as<uint32_t>();
+    const uint32_t* seg_block = c->d_seg_block_cur().as<uint32_t>();
     if (!c->dec_attrs) {
         HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(dec_exit_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kExitLds));
         HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(dec_index_a_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kIndexLds));
@@ -389,9 +400,11 @@ int decode_parallel(mlz_ctx* c, hipStream_t st, const uint8_t* d_src, uint8_t* d
     }
     {
         Timer t(c, T_DEC_PARSE, st);
-        if (segs) HIPCHK(c, hipMemsetAsync(seg_entry, 0xff, size_t(segs) * 4, st));
-        HIPCHK(c, hipMemsetAsync(ws + o_done, 0, total - o_done, st));
-        hipLaunchKernelGGL(dec_header_kernel, dim3((n + 63) / 64), dim3(64), 0, st, d_src, blocks, dec, n, raw_body ? 1 : 0);
+        // the header pass also initialises the workspace words the later passes expect (two memsets = two more launches otherwise)
+        const uint32_t n_ff = segs, n_zero = uint32_t((total - o_done) / 4);
+        const uint32_t hdr_grid = std::max<uint32_t>(uint32_t(n + 63) / 64, std::min<uint32_t>((std::max(n_ff, n_zero) + 255) / 256, 256u));
+        hipLaunchKernelGGL(dec_header_kernel, dim3(hdr_grid), dim3(64), 0, st, d_src, blocks, dec, n, raw_body ? 1 : 0, seg_entry, n_ff,
+                           reinterpret_cast<uint32_t*>(ws + o_done), n_zero);
         if (segs)
             hipLaunchKernelGGL(dec_exit_kernel, dim3(segs), dim3(kExitThreads), kExitLds, st, d_src, blocks, seg_block, dec, exit_tab, rexit_tab);
     }
@@ -449,7 +462,7 @@ int decode_device_locked(mlz_ctx* c, hipStream_t st, const uint8_t* d_src, uint8
         int r = upload_blocks(c, st, desc, n, true, &tiles);
         if (r) return r;
         Timer t(c, T_DEC_SERIAL, st);
-        hipLaunchKernelGGL(decode_serial_kernel, dim3(n), dim3(64), 0, st, d_src, d_dst, c->d_blocks.as<BlockInfo>(), d_out_len, raw_body ? 1 : 0);
+        hipLaunchKernelGGL(decode_serial_kernel, dim3(n), dim3(64), 0, st, d_src, d_dst, c->d_blocks_cur().as<BlockInfo>(), d_out_len, raw_body ? 1 : 0);
         HIPCHK(c, hipGetLastError());
         return 0;
     }
@@ -476,7 +489,7 @@ int crc_device_locked(mlz_ctx* c, hipStream_t st, const uint8_t* d_base, const m
     Timer t(c, T_CRC, st);
     HIPCHK(c, hipMemsetAsync(d_out, 0, sizeof(uint32_t) * n, st));
     const uint32_t groups = uint32_t((maxlen + kCrcGroup - 1) / kCrcGroup);
-    if (groups) hipLaunchKernelGGL(crc_kernel, dim3(groups, n), dim3(256), 0, st, d_base, c->d_blocks.as<BlockInfo>(), pw, d_out);
+    if (groups) hipLaunchKernelGGL(crc_kernel, dim3(groups, n), dim3(256), 0, st, d_base, c->d_blocks_cur().as<BlockInfo>(), pw, d_out);
     hipLaunchKernelGGL(crc_mask_kernel, dim3((n + 255) / 256), dim3(256), 0, st, d_out, n);
     HIPCHK(c, hipGetLastError());
     return 0;
@@ -641,7 +654,7 @@ void mlz_destroy(mlz_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
-    for (DevBuf* b : {&c->d_crc, &c->d_prof, &c->d_blocks, &c->d_tile_block, &c->d_seg_block, &c->d_scratch, &c->d_tile_size, &c->d_tile_out, &c->d_flags, &c->d_far, &c->d_recs, &c->d_piece_cnt, &c->d_dec, &c->d_idx, &c->d_in, &c->d_out, &c->d_len})
+    for (DevBuf* b : {&c->d_crc, &c->d_prof, &c->d_blocks_k[0], &c->d_blocks_k[1], &c->d_tile_block_k[0], &c->d_tile_block_k[1], &c->d_seg_block_k[0], &c->d_seg_block_k[1], &c->d_scratch, &c->d_tile_size, &c->d_tile_out, &c->d_flags, &c->d_far, &c->d_recs, &c->d_piece_cnt, &c->d_dec, &c->d_idx, &c->d_in, &c->d_out, &c->d_len})
         b->release();
     if (c->pinned) (void)hipHostFree(c->pinned);
     if (c->pinned2) (void)hipHostFree(c->pinned2);
@@ -769,6 +782,7 @@ int mlz_set_option(mlz_ctx* c, int opt, int64_t value) {
     case MLZ_OPT_DECODE_ALGO: c->decode_algo = int(value); return 0;
     case MLZ_OPT_ENCODE_FAR: c->encode_far = int(value); return 0;
     case 8: c->general_algo = int(value); return 0;  // 0 = pointer-jumping pass for general blocks (default), 1 = tile chain
+    case 12: c->timer_mask = uint32_t(value); return 0;  // which timers record events (bit = index of mlz_timer_name)
     case 10: c->host_group_enc = size_t(value > 0 ? value : 1) << 20; return 0;  // tuning: MiB per group of a host-pointer encode batch
     case 11: c->host_group_dec = size_t(value > 0 ? value : 1) << 20; return 0;  // ... of a decode batch
     case 9: c->gen_spin_limit = value > 0 ? uint32_t(value) : 1u; return 0;  // grid-barrier patience of the general-block pass, in polls (tests)

@@ -9,7 +9,7 @@ from minlz_amd import synth, _lib
 far = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 ctx = mz.Context(0)
 ctx.set_option(mz.OPT_ENCODE_FAR, far)
-data = synth.text_like(100_000_000, seed=1)
+data = synth.enwik_like(100_000_000, seed=1)
 blocks = [data[o:o + (8 << 20)] for o in range(0, data.size, 8 << 20)]
 L = _lib.lib()
 out = (C.c_ulonglong * 16)()

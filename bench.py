@@ -398,11 +398,13 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tpath):
             tj = json.load(open(tpath))
-            kname = {"enc_tiles": "match_tiles_kernel<true, 4>" if args.level != 2 and args.algo != 2 else "encode_tiles_kernel<true, false, %d>" % (2 if args.level == 2 else 1),
+            kpref = {"enc_tiles": "match_tiles_kernel<true" if args.level != 2 and args.algo != 2 else "encode_tiles_kernel<true, false, %d>" % (2 if args.level == 2 else 1),
                      "dec_exec": "dec_exec2_kernel", "enc_far_build": "far_build_kernel", "dec_parse": "dec_exit_kernel",
                      "enc_serialize": "serialize_pieces_kernel"}.get(dom)
-            if tj.get("workload_bytes") == S and tj.get("workload", "text") == args.workload and not args.file and kname in tj.get("kernels", {}):
-                traffic = tj["kernels"][kname]["traffic"]
+            if kpref and tj.get("workload_bytes") == S and tj.get("workload", "text") == args.workload and not args.file:
+                for kn, kv in tj.get("kernels", {}).items():
+                    if kn.startswith(kpref):
+                        traffic = kv["traffic"]
         roofline = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
                     "algorithmic_bytes_per_launch": alg, "avg_launch_ms": round(kavg[dom], 4)}

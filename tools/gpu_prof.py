@@ -11,7 +11,7 @@ far = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 staged = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 S = 100_000_000; BLOCK = 8 << 20
 ctx = mz.Context(0); ctx.set_option(mz.OPT_ENCODE_FAR, far); ctx.set_option(6, staged); ctx.set_option(1, int(os.environ.get("MLZ_DEC_ALGO", "0")))
-host = synth.text_like(S, 1); dev = torch.device("cuda", 0)
+host = getattr(synth, os.environ.get("MLZ_WORKLOAD", "enwik_like"))(S, 1); dev = torch.device("cuda", 0)
 src = torch.from_numpy(host).to(dev); nblk = (S + BLOCK - 1) // BLOCK; stride = BLOCK + 256
 enc = torch.empty(nblk * stride, dtype=torch.uint8, device=dev); enc_len = torch.zeros(nblk, dtype=torch.int64, device=dev)
 blk_len = [min(BLOCK, S - i * BLOCK) for i in range(nblk)]

@@ -271,10 +271,16 @@ int encode_device_locked(mlz_ctx* c, hipStream_t st, int level, const uint8_t* d
         // LevelBalanced: far matching forced on, both epochs probed and a cost-aware lazy parse (DESIGN.md "Levels").
         // LevelSuperFast: tile-local matches only (no far tables are built or probed).
         const bool far = ((c->encode_far && level != MLZ_LEVEL_SUPERFAST) || level == MLZ_LEVEL_BALANCED) && maxlen > kTile;
-        const uint32_t pattern = level_pattern_of(level == MLZ_LEVEL_BALANCED ? 2 : 1);
+        // the match kernel uses the dense level pattern at every level (DESIGN.md "Tile levels"); the round-1 tile kernel (option 6 = 2)
+        // keeps the fast one at LevelFastest, and the decoder knows both
+        const uint32_t pattern = v2 ? kPatternDense : level_pattern_of(level == MLZ_LEVEL_BALANCED ? 2 : 1);
+        bool any_big = false, any_small = false;
+        for (int i = 0; i < n; i++) (std::min<uint64_t>(desc[i].src_len, kMaxBlockSize) >= kM2BigBlock ? any_big : any_small) = true;
         if (!c->enc_attrs) {  // per context = per device
-            HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(match_tiles_kernel<true, MLZ_M2_NW, kM2HashBitsFast>), hipFuncAttributeMaxDynamicSharedMemorySize, M2Cfg<kM2HashBitsFast>::kLds));
-            HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(match_tiles_kernel<false, MLZ_M2_NW, kM2HashBitsFast>), hipFuncAttributeMaxDynamicSharedMemorySize, M2Cfg<kM2HashBitsFast>::kLds));
+            HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(match_tiles_kernel<true, MLZ_M2_NW, kM2HashBitsBig>), hipFuncAttributeMaxDynamicSharedMemorySize, M2Cfg<kM2HashBitsBig>::kLds));
+            HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(match_tiles_kernel<true, MLZ_M2_NW, kM2HashBitsSmall>), hipFuncAttributeMaxDynamicSharedMemorySize, M2Cfg<kM2HashBitsSmall>::kLds));
+            HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(match_tiles_kernel<false, MLZ_M2_NW, kM2HashBitsBig>), hipFuncAttributeMaxDynamicSharedMemorySize, M2Cfg<kM2HashBitsBig>::kLds));
+            HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(match_tiles_kernel<false, MLZ_M2_NW, kM2HashBitsSmall>), hipFuncAttributeMaxDynamicSharedMemorySize, M2Cfg<kM2HashBitsSmall>::kLds));
             HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(match_tiles_kernel<false, MLZ_M2_NW, kM2HashBitsSuperFast>), hipFuncAttributeMaxDynamicSharedMemorySize, M2Cfg<kM2HashBitsSuperFast>::kLds));
             c->enc_attrs = true;
         }
@@ -296,12 +302,15 @@ int encode_device_locked(mlz_ctx* c, hipStream_t st, int level, const uint8_t* d
             {
                 Timer t(c, T_ENC_TILES, st);
                 const uint32_t grid = ((tiles + 7) / 8) * 8;  // whole rounds of the eight XCDs (see the kernel's workgroup -> tile map)
-#define MLZ_LAUNCH_M2(F, HB)                                                                                                                 \
+#define MLZ_LAUNCH_M2(F, HB, CLS)                                                                                                            \
     hipLaunchKernelGGL((match_tiles_kernel<F, MLZ_M2_NW, HB>), dim3(grid), dim3(256), M2Cfg<HB>::kLds, st, d_src, blocks, tile_block,        \
-                       c->d_recs.as<uint2>(), c->d_piece_cnt.as<uint32_t>(), ftab, epochs, pattern, tiles)
-                if (level == MLZ_LEVEL_SUPERFAST) MLZ_LAUNCH_M2(false, kM2HashBitsSuperFast);
-                else if (far) MLZ_LAUNCH_M2(true, kM2HashBitsFast);
-                else MLZ_LAUNCH_M2(false, kM2HashBitsFast);
+                       c->d_recs.as<uint2>(), c->d_piece_cnt.as<uint32_t>(), ftab, epochs, pattern, tiles, uint32_t(CLS))
+                if (level == MLZ_LEVEL_SUPERFAST) MLZ_LAUNCH_M2(false, kM2HashBitsSuperFast, 2);
+                else {
+                    // one launch per block class that occurs in the batch (usually one)
+                    if (any_big) { if (far) MLZ_LAUNCH_M2(true, kM2HashBitsBig, any_small ? 1 : 2); else MLZ_LAUNCH_M2(false, kM2HashBitsBig, any_small ? 1 : 2); }
+                    if (any_small) { if (far) MLZ_LAUNCH_M2(true, kM2HashBitsSmall, any_big ? 0 : 2); else MLZ_LAUNCH_M2(false, kM2HashBitsSmall, any_big ? 0 : 2); }
+                }
 #undef MLZ_LAUNCH_M2
             }
             {

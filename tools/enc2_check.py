@@ -11,7 +11,7 @@ from minlz_amd import synth
 import oracle as O
 
 def model_body(a, **kw):
-    p = run2.P(**dict(run2.DEF, **kw))
+    p = run2.P(**dict(run2.def_for(a.size), **kw))
     out = np.zeros(a.size + a.size // 8 + 64, dtype=np.uint8)
     n = run2.L.model2_block(a.ctypes.data, a.size, C.byref(p), out.ctypes.data, None)
     return out[:n].tobytes()

@@ -12,7 +12,11 @@ class P(C.Structure):
     _fields_ = [(k, C.c_int) for k in FIELDS] + [('pattern', C.c_uint), ('graded', C.c_int)]
 L.model2_block.restype = C.c_size_t
 L.model2_block.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(P), C.c_void_p, C.c_void_p]
-DEF = dict(sub=4, nw=4, near_bits=13, lazy=3, use_rep=0, far=1, lane_cap=32, back=8, dense=0, skip_shift=10, far_gate=0, seed=1, lazy_cost=1, min_far=8, probe_stride=1, far_stride2=0, lazy_local=1, far_hash24=1, far_prev=0, pattern=0, graded=1)  # = the kernels' defaults
+DEF = dict(sub=4, nw=4, near_bits=12, lazy=3, use_rep=0, far=1, lane_cap=32, back=8, dense=1, skip_shift=10, far_gate=0, seed=1, lazy_cost=1, min_far=8, probe_stride=1, far_stride2=0, lazy_local=1, far_hash24=1, far_prev=0, pattern=0, graded=1)  # = the kernels' defaults for blocks of 1 MiB and more (smaller blocks: near_bits=13, see def_for)
+
+def def_for(nbytes):
+    """The kernels' configuration for a block of nbytes (mlz_encode2.hip.inc: kM2BigBlock)."""
+    return dict(DEF, near_bits=12 if nbytes >= (1 << 20) else 13)
 
 def run(data, check=True, block=8 << 20, **kw):
     d = dict(DEF); d.update(kw); p = P(**d)

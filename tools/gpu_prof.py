@@ -41,6 +41,7 @@ algo = int(os.environ.get("MLZ_DEC_ALGO", "0"))
 if algo == 0:
     names = ["part1-rest(Fstore,long)", "turn-wait", "part2+pass", "other(wait,barrier,flush)", "inputs+parse", "classify+Fissue", "literals+tail", "x"]
     ntiles = sum((l + (32 << 10) - 1) // (32 << 10) for l in blk_len)
+    print("passes/tile %.1f, cycles per pass copy %.0f" % (v[3] / ntiles, v[7] / max(v[3], 1)))
     print("decode (wave 0 of each tile) cycles/tile: " + ", ".join("%s=%.0f" % (n, x / ntiles) for n, x in zip(names, v[:8])), "tiles", ntiles)
 else:
     names = ["loop", "decode+scan", "literals", "classify+wait+Fissue", "N", "Fstore", "S", "n_chunks"]

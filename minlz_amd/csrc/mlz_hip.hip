@@ -355,7 +355,7 @@ int decode_parallel(mlz_ctx* c, hipStream_t st, const uint8_t* d_src, uint8_t* d
     auto al = [](size_t x) { return (x + 255) & ~size_t(255); };
     const size_t o_dec = 0;
     const size_t o_exit = o_dec + al(sizeof(DecBlock) * n);
-    const size_t o_rexit = o_exit + al(size_t(segs) * kSeg * 4);
+    const size_t o_rexit = o_exit + al(size_t(segs) * kExitKeep * 4);
     const size_t o_entry = o_rexit + al(size_t(segs) * kSeg * 2);
     const size_t o_sout = o_entry + al(size_t(segs) * 4);
     const size_t o_slast = o_sout + al(size_t(segs) * 4);
@@ -419,7 +419,7 @@ int decode_parallel(mlz_ctx* c, hipStream_t st, const uint8_t* d_src, uint8_t* d
     }
     {
         Timer t(c, T_DEC_CHAIN, st);
-        hipLaunchKernelGGL(dec_chain_kernel, dim3(n), dim3(kChainThreads), 0, st, blocks, dec, exit_tab, seg_entry, n);
+        hipLaunchKernelGGL(dec_chain_kernel, dim3(n), dim3(kChainThreads), 0, st, blocks, dec, exit_tab, seg_entry, n, d_src, rexit_tab);
     }
     {
         Timer t(c, T_DEC_INDEX, st);

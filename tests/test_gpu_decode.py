@@ -117,6 +117,30 @@ def test_long_tokens_spanning_tiles(ctx):
     assert O.decode_body(tok, len(want)) == (0, bytes(want))
 
 
+def test_dense_token_streams(ctx):
+    # Token streams with far more tokens per stream byte than a compressor writes (1-byte repeats, 2-byte literals, 2-byte
+    # copy1s): the exec pass handles one token per lane in rounds of 64, and groups of four chunks of such streams take three
+    # and more rounds (parts of them while the wave holds the tile's turn).  Output against the oracle's decoder.
+    rng = np.random.default_rng(17)
+    for kind in ("rep1", "mixed", "lit1"):
+        tok = bytearray(O.emit_literal(b"abcdefgh") + O.emit_copy(3, 5))
+        n_out = 8 + 5
+        while n_out < 300000:
+            r = int(rng.integers(0, 3)) if kind == "mixed" else (0 if kind == "rep1" else 1)
+            if r == 0:
+                ln = int(rng.integers(1, 4))
+                tok += O.emit_repeat(ln); n_out += ln
+            elif r == 1:
+                tok += O.emit_literal(bytes([int(rng.integers(0, 256))])); n_out += 1
+            else:
+                off = int(rng.integers(1, 9)); ln = int(rng.integers(4, 8))
+                tok += O.emit_copy(off, ln); n_out += ln
+        code, want = O.decode_body(bytes(tok), n_out)
+        assert code == 0
+        code, got = mz.decode_block(bytes(tok), n_out, ctx)
+        assert code == 0 and got == want, kind
+
+
 def test_decode_block_corrupt_verdicts(ctx):
     # minLZDecode contract (decode.go:178): 0 ok / 1 corrupt, same as the oracle, on mutated streams
     d = synth.text_like(200000, 9)

@@ -20,7 +20,7 @@ using namespace mlz;
 
 namespace {
 constexpr uint32_t kTileLog = 15, kTile = 1u << kTileLog;
-constexpr int kFarBits = 18, kEpochLog = 21, kFarTagBits = 9, kFarStride = 4, kLevels = 4;
+constexpr int kFarBits = 17, kEpochLog = 21, kFarTagBits = 9, kFarStride = 4, kLevels = 4;
 constexpr uint32_t kFarTagMask = (1u << kFarTagBits) - 1;
 constexpr uint32_t kPatternFast = 0xE4E4E4E4u, kPatternDense = 0xEEE7B9E4u;
 inline int tile_level_p(uint32_t t, uint32_t pat) { return int((pat >> (2 * (t & 15))) & 3); }

@@ -429,7 +429,7 @@ int decode_parallel(mlz_ctx* c, hipStream_t st, const uint8_t* d_src, uint8_t* d
         if (segs)
             hipLaunchKernelGGL(dec_index_c_kernel, dim3(segs), dim3(kSegThreads), kIndexLds, st, d_src, blocks, seg_block, dec, seg_entry, seg_out, seg_last,
                                tile_start, tok_mask, chunk_d, chunk_rep, reg_out, reg_last, reg_entry, jump ? &gen->n_general : nullptr);
-        if (tiles) hipLaunchKernelGGL(dec_schedule_kernel, dim3(1), dim3(256), 0, st, blocks, tile_block, dec, order, tiles);
+        if (tiles) hipLaunchKernelGGL(dec_schedule_kernel, dim3(1), dim3(1024), 0, st, blocks, tile_block, dec, order, tiles);
     }
     {
         Timer t(c, T_DEC_EXEC, st);

@@ -178,7 +178,6 @@ def main():
     ap.add_argument("--bytes", type=int, default=100_000_000, help="uncompressed stream bytes per GPU (enwik8 = 1e8)")
     ap.add_argument("--level", type=int, default=1)
     ap.add_argument("--far", type=int, default=1)
-    ap.add_argument("--algo", type=int, default=-1, help="encoder variant (mlz_set_option 6): 0 match + serialize kernels, 2 round-1 wave-per-tile kernel; -1 = library default")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-extras", action="store_true", help="skip the foreign-stream, end-to-end and round-1 stand-in legs")
     ap.add_argument("--workload", default="enwik", choices=["enwik", "text", "json", "random"])
@@ -211,8 +210,6 @@ def main():
 
     ctx = mz.Context(local)
     ctx.set_option(mz.OPT_ENCODE_FAR, args.far)
-    if args.algo >= 0:
-        ctx.set_option(6, args.algo)
 
     if args.mode == "stream":
         return stream_mode(args, ctx, mz, synth, dist, dev, rank, world)
@@ -398,7 +395,7 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tpath):
             tj = json.load(open(tpath))
-            kpref = {"enc_tiles": "match_tiles_kernel<true" if args.level != 2 and args.algo != 2 else "encode_tiles_kernel<true, false, %d>" % (2 if args.level == 2 else 1),
+            kpref = {"enc_tiles": "match_tiles_kernel<true" if args.level != 2 else "encode_tiles_kernel<true, false, 2>",
                      "dec_exec": "dec_exec2_kernel", "enc_far_build": "far_build_kernel", "dec_parse": "dec_exit_kernel",
                      "enc_serialize": "serialize_pieces_kernel"}.get(dom)
             if kpref and tj.get("workload_bytes") == S and tj.get("workload", "text") == args.workload and not args.file:

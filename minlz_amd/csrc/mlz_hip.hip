@@ -121,7 +121,6 @@ struct mlz_ctx {
     // options
     int decode_algo = 0;
     int encode_far = 1;
-    int encode_algo = 0;  // 0 = match + serialize kernels (mlz_encode2.hip.inc), 2 = the round-1 wave-per-tile kernel (always used by LevelBalanced)
     bool enc_attrs = false, far_attr = false, dec_attrs = false, gen_attr = false;  // per device: dynamic-LDS limits raised
     uint32_t timer_mask = 0xffffffffu;  // timers that record events (an event pair costs ~10 us of idle device per kernel boundary)
     int timing = 0;  // 0 off, 1 = the last call's kernel times, 2 = running mean over the calls since it was enabled (no sync per call)
@@ -255,7 +254,11 @@ int encode_device_locked(mlz_ctx* c, hipStream_t st, int level, const uint8_t* d
     if (r) return r;
     // LevelFastest / LevelSuperFast: match + serialize kernels on 8 KiB pieces (mlz_encode2.hip.inc);
     // LevelBalanced (and option 6 = 2): the wave-per-tile kernel of mlz_encode.hip.inc.
-    const bool v2 = level != MLZ_LEVEL_BALANCED && c->encode_algo != 2;
+    // LevelBalanced is still the round-1 wave-per-tile kernel (mlz_encode.hip.inc); everything else, and blocks too short for
+    // far matching at any level, goes through the match + serialize kernels (mlz_encode2.hip.inc)
+    uint64_t maxlen_all = 0;
+    for (int i = 0; i < n; i++) maxlen_all = std::max<uint64_t>(maxlen_all, std::min<uint64_t>(desc[i].src_len, kMaxBlockSize));
+    const bool v2 = level != MLZ_LEVEL_BALANCED || maxlen_all <= kTile;
     const uint32_t sub_log = v2 ? kSubLog : 0;
     const size_t units = size_t(tiles) << sub_log;
     HIPCHK(c, c->d_tile_size.ensure(sizeof(uint32_t) * (units + 1)));
@@ -271,9 +274,7 @@ int encode_device_locked(mlz_ctx* c, hipStream_t st, int level, const uint8_t* d
         // LevelBalanced: far matching forced on, both epochs probed and a cost-aware lazy parse (DESIGN.md "Levels").
         // LevelSuperFast: tile-local matches only (no far tables are built or probed).
         const bool far = ((c->encode_far && level != MLZ_LEVEL_SUPERFAST) || level == MLZ_LEVEL_BALANCED) && maxlen > kTile;
-        // the match kernel uses the dense level pattern at every level (DESIGN.md "Tile levels"); the round-1 tile kernel (option 6 = 2)
-        // keeps the fast one at LevelFastest, and the decoder knows both
-        const uint32_t pattern = v2 ? kPatternDense : level_pattern_of(level == MLZ_LEVEL_BALANCED ? 2 : 1);
+        const uint32_t pattern = kPatternDense;   // every encoder level (DESIGN.md "Tile levels"); the decoder also knows round 1's kPatternFast
         bool any_big = false, any_small = false;
         for (int i = 0; i < n; i++) (std::min<uint64_t>(desc[i].src_len, kMaxBlockSize) >= kM2BigBlock ? any_big : any_small) = true;
         if (!c->enc_attrs) {  // per context = per device
@@ -324,9 +325,7 @@ int encode_device_locked(mlz_ctx* c, hipStream_t st, int level, const uint8_t* d
 #define MLZ_LAUNCH_ENC1(F, LV, LDS)                                                                                                                 \
     hipLaunchKernelGGL((encode_tiles_kernel<F, false, LV>), dim3(tiles), dim3(64), LDS, st, d_src, blocks, tile_block, c->d_scratch.as<uint8_t>(), \
                        c->d_tile_size.as<uint32_t>(), ftab, epochs, prof)
-            if (far && level == MLZ_LEVEL_BALANCED) MLZ_LAUNCH_ENC1(true, 2, kEncLdsTwoWay);
-            else if (far) MLZ_LAUNCH_ENC1(true, 1, kEncLdsInPlace);
-            else MLZ_LAUNCH_ENC1(false, 1, kEncLdsInPlace);
+            MLZ_LAUNCH_ENC1(true, 2, kEncLdsTwoWay);   // (far is always on here: v2 took the batches without far matching)
 #undef MLZ_LAUNCH_ENC1
         }
     }
@@ -795,7 +794,6 @@ int mlz_set_option(mlz_ctx* c, int opt, int64_t value) {
     case 10: c->host_group_enc = size_t(value > 0 ? value : 1) << 20; return 0;  // tuning: MiB per group of a host-pointer encode batch
     case 11: c->host_group_dec = size_t(value > 0 ? value : 1) << 20; return 0;  // ... of a decode batch
     case 9: c->gen_spin_limit = value > 0 ? uint32_t(value) : 1u; return 0;  // grid-barrier patience of the general-block pass, in polls (tests)
-    case 6: c->encode_algo = int(value); return 0;  // 0 = match + serialize kernels (default), 2 = the round-1 wave-per-tile kernel at LevelFastest / LevelSuperFast
     case 3: c->debug_status = int(value); return 0;  // debug: report failure sites in the error code
     case 4: {  // debug: per-phase cycle counters (16 x u64: 0-7 encode, 8-15 decode)
         c->prof_on = value != 0;

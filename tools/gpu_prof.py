@@ -10,7 +10,7 @@ from minlz_amd._lib import BlockDesc
 far = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 staged = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 S = 100_000_000; BLOCK = 8 << 20
-ctx = mz.Context(0); ctx.set_option(mz.OPT_ENCODE_FAR, far); ctx.set_option(6, staged); ctx.set_option(1, int(os.environ.get("MLZ_DEC_ALGO", "0")))
+ctx = mz.Context(0); ctx.set_option(mz.OPT_ENCODE_FAR, far); ctx.set_option(1, int(os.environ.get("MLZ_DEC_ALGO", "0")))
 host = getattr(synth, os.environ.get("MLZ_WORKLOAD", "enwik_like"))(S, 1); dev = torch.device("cuda", 0)
 src = torch.from_numpy(host).to(dev); nblk = (S + BLOCK - 1) // BLOCK; stride = BLOCK + 256
 enc = torch.empty(nblk * stride, dtype=torch.uint8, device=dev); enc_len = torch.zeros(nblk, dtype=torch.int64, device=dev)
@@ -18,15 +18,6 @@ blk_len = [min(BLOCK, S - i * BLOCK) for i in range(nblk)]
 desc = (BlockDesc * nblk)(*[BlockDesc(i * BLOCK, blk_len[i], i * stride, stride) for i in range(nblk)])
 st = torch.cuda.current_stream(dev).cuda_stream
 ctx.encode_batch_device(st, 1, src.data_ptr(), enc.data_ptr(), desc, enc_len.data_ptr()); torch.cuda.synchronize()
-ctx.set_option(4, 1)
-ctx.encode_batch_device(st, 1, src.data_ptr(), enc.data_ptr(), desc, enc_len.data_ptr()); torch.cuda.synchronize()
-buf = (C.c_uint64 * 16)(); ctx.set_option(5, C.addressof(buf))
-v = list(buf)
-names = ["stage", "near", "far", "select", "emit", "tail", "n_matches", "n_steps"]
-tot = sum(v[:6])
-print("far=%d staged=%d" % (far, staged), {n: x for n, x in zip(names, v[:8])})
-print("cycles/step: " + ", ".join("%s=%.0f" % (n, x / max(v[7], 1)) for n, x in zip(names[:6], v[:6])), "matches/step=%.2f" % (v[6] / max(v[7], 1)), "total/step=%.0f" % (tot / max(v[7], 1)))
-
 # ---- decode ----
 lens = enc_len.cpu().tolist()
 dec = torch.empty(S + 256, dtype=torch.uint8, device=dev); dec_len = torch.zeros(nblk, dtype=torch.int64, device=dev)

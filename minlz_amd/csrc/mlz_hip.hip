@@ -401,7 +401,7 @@ int decode_parallel(mlz_ctx* c, hipStream_t st, const uint8_t* d_src, uint8_t* d
     if (!c->dec_attrs) {
         HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(dec_exit_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kExitLds));
         HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(dec_index_a_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kIndexLds));
-        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(dec_index_c_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kIndexLds));
+        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(dec_index_c_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kIndexCLds));
         HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(dec_exec_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kTile));
         HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(dec_exec2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kExecLds));
         c->dec_attrs = true;
@@ -426,7 +426,7 @@ int decode_parallel(mlz_ctx* c, hipStream_t st, const uint8_t* d_src, uint8_t* d
             hipLaunchKernelGGL(dec_index_a_kernel, dim3(segs), dim3(kSegThreads), kIndexLds, st, d_src, blocks, seg_block, dec, seg_entry, seg_out, seg_last, rexit_tab, reg_out, reg_last, reg_entry);
         hipLaunchKernelGGL(dec_index_b_kernel, dim3(n), dim3(64), 0, st, blocks, dec, seg_out, seg_last, seg_entry, n);
         if (segs)
-            hipLaunchKernelGGL(dec_index_c_kernel, dim3(segs), dim3(kSegThreads), kIndexLds, st, d_src, blocks, seg_block, dec, seg_entry, seg_out, seg_last,
+            hipLaunchKernelGGL(dec_index_c_kernel, dim3(segs), dim3(kSegThreads), kIndexCLds, st, d_src, blocks, seg_block, dec, seg_entry, seg_out, seg_last,
                                tile_start, tok_mask, chunk_d, chunk_rep, reg_out, reg_last, reg_entry, jump ? &gen->n_general : nullptr);
         if (tiles) hipLaunchKernelGGL(dec_schedule_kernel, dim3(1), dim3(1024), 0, st, blocks, tile_block, dec, order, tiles);
     }

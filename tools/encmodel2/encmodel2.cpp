@@ -20,6 +20,7 @@ using namespace mlz;
 
 namespace {
 constexpr uint32_t kTileLog = 15, kTile = 1u << kTileLog;
+constexpr uint32_t kSeedStride = 2;
 constexpr int kFarBits = 17, kEpochLog = 21, kFarTagBits = 9, kFarStride = 4, kLevels = 4;
 constexpr uint32_t kFarTagMask = (1u << kFarTagBits) - 1;
 constexpr uint32_t kPatternFast = 0xE4E4E4E4u, kPatternDense = 0xEEE7B9E4u;
@@ -119,7 +120,7 @@ size_t model2_block(const uint8_t* src, size_t n, const Params* P, uint8_t* out,
             const uint32_t tsize = P->graded ? uint32_t(((ps / piece_len) + 1) * (table.size() / size_t(P->sub))) : uint32_t(table.size());
             auto tix = [&](uint32_t h) -> uint32_t { return uint32_t((uint64_t(h) * tsize) >> P->near_bits); };
             if (P->seed)
-                for (uint32_t p = 0; p < ps; p++) {
+                for (uint32_t p = 0; p < ps; p += kSeedStride) {   // every kSeedStride-th earlier position (mlz_encode2.hip.inc)
                     const uint32_t h1 = hash4(ld64z(s, p, tl), P->near_bits + 1);
                     table[tix(h1 >> 1)] = uint16_t(p | ((h1 & 1) << 15));
                 }

@@ -395,7 +395,7 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tpath):
             tj = json.load(open(tpath))
-            kpref = {"enc_tiles": "match_tiles_kernel<true" if args.level != 2 else "encode_tiles_kernel<true, false, 2>",
+            kpref = {"enc_tiles": "match_tiles_kernel<true",
                      "dec_exec": "dec_exec2_kernel", "enc_far_build": "far_build_kernel", "dec_parse": "dec_exit_kernel",
                      "enc_serialize": "serialize_pieces_kernel"}.get(dom)
             if kpref and tj.get("workload_bytes") == S and tj.get("workload", "text") == args.workload and not args.file:

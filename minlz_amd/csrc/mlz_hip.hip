@@ -252,14 +252,10 @@ int encode_device_locked(mlz_ctx* c, hipStream_t st, int level, const uint8_t* d
     uint32_t tiles = 0;
     int r = upload_blocks(c, st, desc, n, false, &tiles, nullptr, mirror);
     if (r) return r;
-    // LevelFastest / LevelSuperFast: match + serialize kernels on 8 KiB pieces (mlz_encode2.hip.inc);
-    // LevelBalanced (and option 6 = 2): the wave-per-tile kernel of mlz_encode.hip.inc.
-    // LevelBalanced is still the round-1 wave-per-tile kernel (mlz_encode.hip.inc); everything else, and blocks too short for
-    // far matching at any level, goes through the match + serialize kernels (mlz_encode2.hip.inc)
-    uint64_t maxlen_all = 0;
-    for (int i = 0; i < n; i++) maxlen_all = std::max<uint64_t>(maxlen_all, std::min<uint64_t>(desc[i].src_len, kMaxBlockSize));
-    const bool v2 = level != MLZ_LEVEL_BALANCED || maxlen_all <= kTile;
-    const uint32_t sub_log = v2 ? kSubLog : 0;
+    // Every level goes through the match + serialize kernels on 8 KiB pieces (mlz_encode2.hip.inc); LevelBalanced is their
+    // configuration with larger near tables, denser far tables and a second far probe (kL2*).
+    const bool l2new = level == MLZ_LEVEL_BALANCED;
+    const uint32_t sub_log = kSubLog;
     const size_t units = size_t(tiles) << sub_log;
     HIPCHK(c, c->d_tile_size.ensure(sizeof(uint32_t) * (units + 1)));
     HIPCHK(c, c->d_tile_out.ensure(sizeof(uint32_t) * (units + 1)));
@@ -267,7 +263,7 @@ int encode_device_locked(mlz_ctx* c, hipStream_t st, int level, const uint8_t* d
     const BlockInfo* blocks = c->d_blocks_cur().as<BlockInfo>();
     const uint32_t* tile_block = c->d_tile_block_cur().as<uint32_t>();
     if (level != MLZ_LEVEL_UNCOMPRESSED && tiles > 0) {
-        HIPCHK(c, c->d_scratch.ensure(v2 ? units * kPieceScratch : size_t(tiles) * kTileScratch));
+        HIPCHK(c, c->d_scratch.ensure(units * kPieceScratch));
         uint64_t maxlen = 0;
         for (int i = 0; i < n; i++) maxlen = std::max<uint64_t>(maxlen, std::min<uint64_t>(desc[i].src_len, kMaxBlockSize));
         const uint32_t epochs = uint32_t((maxlen + (1u << kEpochLog) - 1) >> kEpochLog);
@@ -283,21 +279,28 @@ int encode_device_locked(mlz_ctx* c, hipStream_t st, int level, const uint8_t* d
             HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(match_tiles_kernel<false, MLZ_M2_NW, kM2HashBitsBig>), hipFuncAttributeMaxDynamicSharedMemorySize, M2Cfg<kM2HashBitsBig>::kLds));
             HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(match_tiles_kernel<false, MLZ_M2_NW, kM2HashBitsSmall>), hipFuncAttributeMaxDynamicSharedMemorySize, M2Cfg<kM2HashBitsSmall>::kLds));
             HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(match_tiles_kernel<false, MLZ_M2_NW, kM2HashBitsSuperFast>), hipFuncAttributeMaxDynamicSharedMemorySize, M2Cfg<kM2HashBitsSuperFast>::kLds));
+            HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(match_tiles_kernel<true, MLZ_M2_NW, kM2HashBitsSmall, kL2FarBits, true>), hipFuncAttributeMaxDynamicSharedMemorySize, M2Cfg<kM2HashBitsSmall>::kLds));
             c->enc_attrs = true;
         }
         if (far) {
             Timer t(c, T_FAR, st);
-            const size_t words = (size_t(n) * (kLevels - 1) * epochs) << kFarBits;
+            const int fbits = l2new ? kL2FarBits : kFarBits;
+            const size_t words = (size_t(n) * (kLevels - 1) * epochs) << fbits;
             HIPCHK(c, c->d_far.ensure(words * 4));
             if (!c->far_attr) {
-                HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(far_build_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 4u << kFarSliceBits));
+                HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(far_build_kernel<kFarBits, kFarStride>), hipFuncAttributeMaxDynamicSharedMemorySize, 4u << kFarSliceBits));
+                HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(far_build_kernel<kL2FarBits, kL2FarStride>), hipFuncAttributeMaxDynamicSharedMemorySize, 4u << kFarSliceBits));
                 c->far_attr = true;
             }
-            hipLaunchKernelGGL(far_build_kernel, dim3(kFarSlices, epochs, n), dim3(1024), 4u << kFarSliceBits, st, d_src, blocks,
-                               c->d_far.as<uint32_t>(), epochs, pattern);
+            if (l2new)
+                hipLaunchKernelGGL((far_build_kernel<kL2FarBits, kL2FarStride>), dim3(far_slices(kL2FarBits), epochs, n), dim3(1024), 4u << kFarSliceBits, st, d_src, blocks,
+                                   c->d_far.as<uint32_t>(), epochs, pattern);
+            else
+                hipLaunchKernelGGL((far_build_kernel<kFarBits, kFarStride>), dim3(far_slices(kFarBits), epochs, n), dim3(1024), 4u << kFarSliceBits, st, d_src, blocks,
+                                   c->d_far.as<uint32_t>(), epochs, pattern);
         }
         const uint32_t* ftab = far ? c->d_far.as<uint32_t>() : nullptr;
-        if (v2) {
+        {
             HIPCHK(c, c->d_recs.ensure(units * kRecPerPiece * sizeof(uint2)));
             HIPCHK(c, c->d_piece_cnt.ensure(units * sizeof(uint32_t)));
             {
@@ -307,6 +310,10 @@ int encode_device_locked(mlz_ctx* c, hipStream_t st, int level, const uint8_t* d
     hipLaunchKernelGGL((match_tiles_kernel<F, MLZ_M2_NW, HB>), dim3(grid), dim3(256), M2Cfg<HB>::kLds, st, d_src, blocks, tile_block,        \
                        c->d_recs.as<uint2>(), c->d_piece_cnt.as<uint32_t>(), ftab, epochs, pattern, tiles, uint32_t(CLS))
                 if (level == MLZ_LEVEL_SUPERFAST) MLZ_LAUNCH_M2(false, kM2HashBitsSuperFast, 2);
+                else if (l2new && far)
+                    hipLaunchKernelGGL((match_tiles_kernel<true, MLZ_M2_NW, kM2HashBitsSmall, kL2FarBits, true>), dim3(grid), dim3(256), M2Cfg<kM2HashBitsSmall>::kLds, st,
+                                       d_src, blocks, tile_block, c->d_recs.as<uint2>(), c->d_piece_cnt.as<uint32_t>(), ftab, epochs, pattern, tiles, 2u);
+                else if (l2new) MLZ_LAUNCH_M2(false, kM2HashBitsSmall, 2);
                 else {
                     // one launch per block class that occurs in the batch (usually one)
                     if (any_big) { if (far) MLZ_LAUNCH_M2(true, kM2HashBitsBig, any_small ? 1 : 2); else MLZ_LAUNCH_M2(false, kM2HashBitsBig, any_small ? 1 : 2); }
@@ -319,14 +326,6 @@ int encode_device_locked(mlz_ctx* c, hipStream_t st, int level, const uint8_t* d
                 hipLaunchKernelGGL(serialize_pieces_kernel, dim3(tiles), dim3(256), kSerLds, st, d_src, blocks, tile_block, c->d_recs.as<uint2>(),
                                    c->d_piece_cnt.as<uint32_t>(), c->d_scratch.as<uint8_t>(), c->d_tile_size.as<uint32_t>());
             }
-        } else {
-            Timer t(c, T_ENC_TILES, st);
-            unsigned long long* prof = c->prof_on ? c->d_prof.as<unsigned long long>() : nullptr;
-#define MLZ_LAUNCH_ENC1(F, LV, LDS)                                                                                                                 \
-    hipLaunchKernelGGL((encode_tiles_kernel<F, false, LV>), dim3(tiles), dim3(64), LDS, st, d_src, blocks, tile_block, c->d_scratch.as<uint8_t>(), \
-                       c->d_tile_size.as<uint32_t>(), ftab, epochs, prof)
-            MLZ_LAUNCH_ENC1(true, 2, kEncLdsTwoWay);   // (far is always on here: v2 took the batches without far matching)
-#undef MLZ_LAUNCH_ENC1
         }
     }
     {
@@ -336,10 +335,8 @@ int encode_device_locked(mlz_ctx* c, hipStream_t st, int level, const uint8_t* d
     }
     if (tiles > 0) {
         Timer t(c, T_ENC_GATHER, st);
-        if (v2) hipLaunchKernelGGL(encode_gather2_kernel, dim3(tiles), dim3(256), 0, st, d_src, blocks, tile_block, c->d_scratch.as<uint8_t>(),
-                                   c->d_tile_size.as<uint32_t>(), c->d_tile_out.as<uint32_t>(), d_dst, c->d_flags.as<uint32_t>(), with_header ? 1 : 0);
-        else hipLaunchKernelGGL(encode_gather_kernel, dim3(tiles), dim3(256), 0, st, d_src, blocks, tile_block, c->d_scratch.as<uint8_t>(),
-                                c->d_tile_size.as<uint32_t>(), c->d_tile_out.as<uint32_t>(), d_dst, c->d_flags.as<uint32_t>(), with_header ? 1 : 0);
+        hipLaunchKernelGGL(encode_gather2_kernel, dim3(tiles), dim3(256), 0, st, d_src, blocks, tile_block, c->d_scratch.as<uint8_t>(),
+                           c->d_tile_size.as<uint32_t>(), c->d_tile_out.as<uint32_t>(), d_dst, c->d_flags.as<uint32_t>(), with_header ? 1 : 0);
     }
     HIPCHK(c, hipGetLastError());
     return 0;

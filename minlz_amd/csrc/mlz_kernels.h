@@ -16,7 +16,6 @@ namespace mlz {
 #endif
 constexpr int kTileLog = MLZ_TILE_LOG;
 constexpr uint32_t kTile = 1u << kTileLog;           // 32 KiB of uncompressed data
-constexpr uint32_t kTileScratch = kTile + kTile / 16 + 2048;  // worst-case tokens per tile + flush slack (multiple of 16)
 
 struct BlockInfo {
     uint64_t src_off, src_len, dst_off, dst_cap;

@@ -10,8 +10,8 @@ import minlz_amd as mz
 from minlz_amd import synth
 import oracle as O
 
-def model_body(a, **kw):
-    p = run2.P(**dict(run2.def_for(a.size), **kw))
+def model_body(a, level=1, **kw):
+    p = run2.P(**dict(run2.def_for(a.size, level), **kw))
     out = np.zeros(a.size + a.size // 8 + 64, dtype=np.uint8)
     n = run2.L.model2_block(a.ctypes.data, a.size, C.byref(p), out.ctypes.data, None)
     return out[:n].tobytes()
@@ -32,9 +32,9 @@ def main():
     pat = np.tile(np.frombuffer(b"abcdefghij", dtype=np.uint8), 30000)
     cases.append(("period10", pat))
     bad = 0
-    for name, data in cases:
+    for name, data, level in [(n_, d_, 1) for n_, d_ in cases] + [(n_ + "/L2", d_, 2) for n_, d_ in cases if len(d_) >= 40000]:
         a = np.ascontiguousarray(np.frombuffer(bytes(data), dtype=np.uint8) if not isinstance(data, np.ndarray) else data)
-        enc = mz.Encode(a, mz.LevelFastest, ctx)
+        enc = mz.Encode(a, mz.LevelFastest if level == 1 else mz.LevelBalanced, ctx)
         ok_rt = O.decode(enc) == a.tobytes()
         msg = ""
         if a.size >= 16 and not (len(enc) >= 2 and enc[0] == 0 and enc[1] == 0 and len(enc) == a.size + 2):
@@ -43,7 +43,7 @@ def main():
             while enc[hl] & 0x80: hl += 1
             hl += 1
             body = bytes(enc[hl:])
-            mb = model_body(a)
+            mb = model_body(a, level)
             if body != mb:
                 k = next((i for i in range(min(len(body), len(mb))) if body[i] != mb[i]), min(len(body), len(mb)))
                 msg = " MODEL DIFF at %d (gpu %d B, model %d B)" % (k, len(body), len(mb))

@@ -20,8 +20,7 @@ using namespace mlz;
 
 namespace {
 constexpr uint32_t kTileLog = 15, kTile = 1u << kTileLog;
-constexpr uint32_t kSeedStride = 2;
-constexpr int kFarBits = 17, kEpochLog = 21, kFarTagBits = 9, kFarStride = 4, kLevels = 4;
+constexpr int kEpochLog = 21, kFarTagBits = 9, kLevels = 4;
 constexpr uint32_t kFarTagMask = (1u << kFarTagBits) - 1;
 constexpr uint32_t kPatternFast = 0xE4E4E4E4u, kPatternDense = 0xEEE7B9E4u;
 inline int tile_level_p(uint32_t t, uint32_t pat) { return int((pat >> (2 * (t & 15))) & 3); }
@@ -74,6 +73,9 @@ struct Params {
     int far_prev;     // 1: the previous epoch's table is probed as well (LevelBalanced)
     unsigned pattern; // != 0: level pattern override (2 bits per tile, period 16)
     int graded;       // 1: piece k of a tile has (k+1)/sub of the near-table entries (same positions-per-entry for every piece)
+    int far_bits;     // far table entries per (epoch, level set), log2 (LevelFastest 17, LevelBalanced 18)
+    int far_stride;   // every far_stride-th 8-byte window is entered into the far tables (4 / 2)
+    int seed_stride;  // every seed_stride-th earlier position of the tile seeds a piece's near table (2 / 1)
 };
 
 struct Rec { uint32_t mp, len, off; };
@@ -85,12 +87,13 @@ extern "C" {
 size_t model2_block(const uint8_t* src, size_t n, const Params* P, uint8_t* out, uint64_t* stats) {
     g_hash24 = P->far_hash24;
     const uint32_t pat = P->pattern ? P->pattern : P->dense ? kPatternDense : kPatternFast;
+    const int kFarBits = P->far_bits;
     const size_t ntiles = (n + kTile - 1) >> kTileLog;
     const size_t nepoch = (n + (size_t(1) << kEpochLog) - 1) >> kEpochLog;
     std::vector<uint32_t> far_tab;
     if (P->far && n > kTile) {
         far_tab.assign(size_t(kLevels - 1) * nepoch << kFarBits, 0xffffffffu);
-        for (size_t q = 0; q + 8 <= n; q += kFarStride) {
+        for (size_t q = 0; q + 8 <= n; q += size_t(P->far_stride)) {
             uint64_t v; memcpy(&v, src + q, 8);
             const FarHash fh = far_hash(v, kFarBits);
             const int lv = tile_level_p(uint32_t(q >> kTileLog), pat);
@@ -120,7 +123,7 @@ size_t model2_block(const uint8_t* src, size_t n, const Params* P, uint8_t* out,
             const uint32_t tsize = P->graded ? uint32_t(((ps / piece_len) + 1) * (table.size() / size_t(P->sub))) : uint32_t(table.size());
             auto tix = [&](uint32_t h) -> uint32_t { return uint32_t((uint64_t(h) * tsize) >> P->near_bits); };
             if (P->seed)
-                for (uint32_t p = 0; p < ps; p += kSeedStride) {   // every kSeedStride-th earlier position (mlz_encode2.hip.inc)
+                for (uint32_t p = 0; p < ps; p += uint32_t(P->seed_stride)) {   // (mlz_encode2.hip.inc: kSeedStride)
                     const uint32_t h1 = hash4(ld64z(s, p, tl), P->near_bits + 1);
                     table[tix(h1 >> 1)] = uint16_t(p | ((h1 & 1) << 15));
                 }

@@ -1,0 +1,48 @@
+"""The device encoder against its CPU model (tools/encmodel2: a sequential statement of exactly the match + serialize
+kernels' algorithm, test infrastructure like the oracle): block bodies must be byte-identical at LevelFastest and
+LevelBalanced, for both block classes (>= 1 MiB: 12-bit near tables; smaller: 13-bit)."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import minlz_amd as mz
+from minlz_amd import synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def model():
+    sys.path.insert(0, os.path.join(ROOT, "tools", "encmodel2"))
+    import run2  # compiles the model with g++ on import
+    return run2
+
+
+def _body(enc):
+    assert enc[0] == 0
+    h = 1
+    while enc[h] & 0x80:
+        h += 1
+    return bytes(enc[h + 1:])
+
+
+def _model_body(run2, a, level):
+    p = run2.P(**run2.def_for(a.size, level))
+    out = np.zeros(a.size + a.size // 8 + 64, dtype=np.uint8)
+    n = run2.L.model2_block(a.ctypes.data, a.size, C.byref(p), out.ctypes.data, None)
+    return out[:n].tobytes()
+
+
+@pytest.mark.parametrize("level", [1, 2])
+def test_device_output_equals_the_model(ctx, model, level):
+    rng = np.random.default_rng(9)
+    mix = np.concatenate([synth.text_like(200000, 4), rng.integers(0, 256, 100000, dtype=np.uint8), synth.json_like(150000, 5)])
+    cases = [synth.text_like(100000, 7), synth.text_like((1 << 20) + 77, 8), mix, synth.json_like(3 << 20, 2)]
+    for a in cases:
+        a = np.ascontiguousarray(a)
+        enc = mz.Encode(a, mz.LevelFastest if level == 1 else mz.LevelBalanced, ctx)
+        assert _body(enc) == _model_body(model, a, level), (level, a.size)

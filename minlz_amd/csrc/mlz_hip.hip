@@ -280,6 +280,7 @@ int encode_device_locked(mlz_ctx* c, hipStream_t st, int level, const uint8_t* d
             HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(match_tiles_kernel<false, MLZ_M2_NW, kM2HashBitsSmall>), hipFuncAttributeMaxDynamicSharedMemorySize, M2Cfg<kM2HashBitsSmall>::kLds));
             HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(match_tiles_kernel<false, MLZ_M2_NW, kM2HashBitsSuperFast>), hipFuncAttributeMaxDynamicSharedMemorySize, M2Cfg<kM2HashBitsSuperFast>::kLds));
             HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(match_tiles_kernel<true, MLZ_M2_NW, kM2HashBitsSmall, kL2FarBits, true>), hipFuncAttributeMaxDynamicSharedMemorySize, M2Cfg<kM2HashBitsSmall>::kLds));
+            HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(match_tiles_kernel<false, MLZ_M2_NW, kM2HashBitsSmall, kL2FarBits, true>), hipFuncAttributeMaxDynamicSharedMemorySize, M2Cfg<kM2HashBitsSmall>::kLds));
             c->enc_attrs = true;
         }
         if (far) {
@@ -313,7 +314,9 @@ int encode_device_locked(mlz_ctx* c, hipStream_t st, int level, const uint8_t* d
                 else if (l2new && far)
                     hipLaunchKernelGGL((match_tiles_kernel<true, MLZ_M2_NW, kM2HashBitsSmall, kL2FarBits, true>), dim3(grid), dim3(256), M2Cfg<kM2HashBitsSmall>::kLds, st,
                                        d_src, blocks, tile_block, c->d_recs.as<uint2>(), c->d_piece_cnt.as<uint32_t>(), ftab, epochs, pattern, tiles, 2u);
-                else if (l2new) MLZ_LAUNCH_M2(false, kM2HashBitsSmall, 2);
+                else if (l2new)   // blocks of one tile: no far tables, but the same near-table seeding as the level's other blocks
+                    hipLaunchKernelGGL((match_tiles_kernel<false, MLZ_M2_NW, kM2HashBitsSmall, kL2FarBits, true>), dim3(grid), dim3(256), M2Cfg<kM2HashBitsSmall>::kLds, st,
+                                       d_src, blocks, tile_block, c->d_recs.as<uint2>(), c->d_piece_cnt.as<uint32_t>(), ftab, epochs, pattern, tiles, 2u);
                 else {
                     // one launch per block class that occurs in the batch (usually one)
                     if (any_big) { if (far) MLZ_LAUNCH_M2(true, kM2HashBitsBig, any_small ? 1 : 2); else MLZ_LAUNCH_M2(false, kM2HashBitsBig, any_small ? 1 : 2); }

@@ -32,7 +32,7 @@ def main():
     pat = np.tile(np.frombuffer(b"abcdefghij", dtype=np.uint8), 30000)
     cases.append(("period10", pat))
     bad = 0
-    for name, data, level in [(n_, d_, 1) for n_, d_ in cases] + [(n_ + "/L2", d_, 2) for n_, d_ in cases if len(d_) >= 40000]:
+    for name, data, level in [(n_, d_, 1) for n_, d_ in cases] + [(n_ + "/L2", d_, 2) for n_, d_ in cases if len(d_) >= 8000]:
         a = np.ascontiguousarray(np.frombuffer(bytes(data), dtype=np.uint8) if not isinstance(data, np.ndarray) else data)
         enc = mz.Encode(a, mz.LevelFastest if level == 1 else mz.LevelBalanced, ctx)
         ok_rt = O.decode(enc) == a.tobytes()

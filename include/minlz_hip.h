@@ -127,7 +127,7 @@ int64_t mlz_stream_decoded_len(const uint8_t* src, size_t n); /* host-only chunk
 int64_t mlz_stream_decode(mlz_ctx* ctx, uint32_t flags, const uint8_t* src, size_t n, uint8_t* dst, size_t dst_cap);
 
 /* ---- tuning / introspection (not part of the reference surface) ---- */
-#define MLZ_OPT_DECODE_ALGO 1  /* 0 = parallel (default), 1 = serial one-wave-per-block */
+#define MLZ_OPT_DECODE_ALGO 1  /* 0 = parallel (default), 1 = serial one-wave-per-block, 3 = parallel with every block on the tile path (cross-checks) */
 #define MLZ_OPT_ENCODE_FAR 2   /* 0 = tile-local matches only, 1 = + far matches (default) */
 int mlz_set_option(mlz_ctx* ctx, int opt, int64_t value);
 /* Milliseconds spent in each kernel family, measured with HIP events on the caller's stream.

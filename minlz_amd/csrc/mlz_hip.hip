@@ -402,7 +402,6 @@ int decode_parallel(mlz_ctx* c, hipStream_t st, const uint8_t* d_src, uint8_t* d
         HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(dec_exit_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kExitLds));
         HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(dec_index_a_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kIndexLds));
         HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(dec_index_c_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kIndexCLds));
-        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(dec_exec_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kTile));
         HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(dec_exec2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kExecLds));
         c->dec_attrs = true;
     }
@@ -433,10 +432,7 @@ int decode_parallel(mlz_ctx* c, hipStream_t st, const uint8_t* d_src, uint8_t* d
     {
         Timer t(c, T_DEC_EXEC, st);
         unsigned long long* prof = c->prof_on ? c->d_prof.as<unsigned long long>() : nullptr;
-        if (tiles && c->decode_algo == 2)  // previous exec pass: one wave per tile, single phase
-            hipLaunchKernelGGL(dec_exec_kernel, dim3(tiles), dim3(64), kTile, st, d_src, d_dst, blocks, tile_block, dec, tile_start, tok_mask, order, tile_done, ticket,
-                               tiles, prof);
-        else if (tiles)
+        if (tiles)
             hipLaunchKernelGGL(dec_exec2_kernel, dim3(tiles), dim3(kExecThreads), kExecLds, st, d_src, d_dst, blocks, tile_block, dec, tile_start, tok_mask,
                                chunk_d, chunk_rep, order, tile_done, ticket, tiles, prof);
         if (jump && segs) {  // returns at once unless D3c flagged a general block

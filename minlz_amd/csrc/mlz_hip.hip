@@ -275,30 +275,50 @@ int encode_device_locked(mlz_ctx* c, hipStream_t st, int level, const uint8_t* d
         for (int i = 0; i < n; i++) (std::min<uint64_t>(desc[i].src_len, kMaxBlockSize) >= kM2BigBlock ? any_big : any_small) = true;
         if (!c->enc_attrs) {  // per context = per device
             HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(match_tiles_kernel<true, MLZ_M2_NW, kM2HashBitsBig>), hipFuncAttributeMaxDynamicSharedMemorySize, M2Cfg<kM2HashBitsBig>::kLds));
-            HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(match_tiles_kernel<true, MLZ_M2_NW, kM2HashBitsSmall>), hipFuncAttributeMaxDynamicSharedMemorySize, M2Cfg<kM2HashBitsSmall>::kLds));
+            HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(match_tiles_kernel<true, MLZ_M2_NW, kM2HashBitsSmall, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, M2Cfg<kM2HashBitsSmall>::kLds));
             HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(match_tiles_kernel<false, MLZ_M2_NW, kM2HashBitsBig>), hipFuncAttributeMaxDynamicSharedMemorySize, M2Cfg<kM2HashBitsBig>::kLds));
             HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(match_tiles_kernel<false, MLZ_M2_NW, kM2HashBitsSmall>), hipFuncAttributeMaxDynamicSharedMemorySize, M2Cfg<kM2HashBitsSmall>::kLds));
             HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(match_tiles_kernel<false, MLZ_M2_NW, kM2HashBitsSuperFast>), hipFuncAttributeMaxDynamicSharedMemorySize, M2Cfg<kM2HashBitsSuperFast>::kLds));
             HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(match_tiles_kernel<true, MLZ_M2_NW, kM2HashBitsSmall, kL2FarBits, true>), hipFuncAttributeMaxDynamicSharedMemorySize, M2Cfg<kM2HashBitsSmall>::kLds));
+            HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(match_tiles_kernel<true, MLZ_M2_NW, kM2HashBitsSmall, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, M2Cfg<kM2HashBitsSmall>::kLds));
             HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(match_tiles_kernel<false, MLZ_M2_NW, kM2HashBitsSmall, kL2FarBits, true>), hipFuncAttributeMaxDynamicSharedMemorySize, M2Cfg<kM2HashBitsSmall>::kLds));
             c->enc_attrs = true;
         }
+        // LevelFastest: blocks below 1 MiB have far tables that go with their length (small_far_bits); the tables of a batch
+        // are as far apart as its largest block needs
+        const int fbits = any_big ? (l2new ? kL2FarBits : kFarBits) : small_far_bits(maxlen) + (l2new ? 1 : 0);
         if (far) {
             Timer t(c, T_FAR, st);
-            const int fbits = l2new ? kL2FarBits : kFarBits;
             const size_t words = (size_t(n) * (kLevels - 1) * epochs) << fbits;
             HIPCHK(c, c->d_far.ensure(words * 4));
             if (!c->far_attr) {
                 HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(far_build_kernel<kFarBits, kFarStride>), hipFuncAttributeMaxDynamicSharedMemorySize, 4u << kFarSliceBits));
+                HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(far_build_kernel<0, kFarStride>), hipFuncAttributeMaxDynamicSharedMemorySize, 4u << kFarSliceBits));
+                HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(far_build_kernel<0, kL2FarStride>), hipFuncAttributeMaxDynamicSharedMemorySize, 4u << kFarSliceBits));
                 HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(far_build_kernel<kL2FarBits, kL2FarStride>), hipFuncAttributeMaxDynamicSharedMemorySize, 4u << kFarSliceBits));
                 c->far_attr = true;
             }
-            if (l2new)
-                hipLaunchKernelGGL((far_build_kernel<kL2FarBits, kL2FarStride>), dim3(far_slices(kL2FarBits), epochs, n), dim3(1024), 4u << kFarSliceBits, st, d_src, blocks,
-                                   c->d_far.as<uint32_t>(), epochs, pattern);
-            else
-                hipLaunchKernelGGL((far_build_kernel<kFarBits, kFarStride>), dim3(far_slices(kFarBits), epochs, n), dim3(1024), 4u << kFarSliceBits, st, d_src, blocks,
-                                   c->d_far.as<uint32_t>(), epochs, pattern);
+            if (any_big) {
+                if (l2new)
+                    hipLaunchKernelGGL((far_build_kernel<kL2FarBits, kL2FarStride>), dim3(far_slices(kL2FarBits), epochs, n), dim3(1024), 4u << kFarSliceBits, st, d_src,
+                                       blocks, c->d_far.as<uint32_t>(), epochs, pattern, uint32_t(fbits), any_small ? 1u : 2u);
+                else
+                    hipLaunchKernelGGL((far_build_kernel<kFarBits, kFarStride>), dim3(far_slices(kFarBits), epochs, n), dim3(1024), 4u << kFarSliceBits, st, d_src,
+                                       blocks, c->d_far.as<uint32_t>(), epochs, pattern, uint32_t(fbits), any_small ? 1u : 2u);
+            }
+            if (any_small) {
+                uint64_t max_small = 0;
+                for (int i = 0; i < n; i++) if (desc[i].src_len < kBigBlock) max_small = std::max<uint64_t>(max_small, desc[i].src_len);
+                const int sb = small_far_bits(max_small) + (l2new ? 1 : 0);
+                const uint32_t lds = 4u << std::min<int>(sb, kFarSliceBits);   // small tables leave room for more workgroups per CU
+                const dim3 grid(1u << (std::max<int>(sb, kFarSliceBits) - kFarSliceBits), 1, n);
+                if (l2new)
+                    hipLaunchKernelGGL((far_build_kernel<0, kL2FarStride>), grid, dim3(1024), lds, st, d_src, blocks, c->d_far.as<uint32_t>(), epochs, pattern,
+                                       uint32_t(fbits), any_big ? 0u : 2u);
+                else
+                    hipLaunchKernelGGL((far_build_kernel<0, kFarStride>), grid, dim3(1024), lds, st, d_src, blocks, c->d_far.as<uint32_t>(), epochs, pattern,
+                                       uint32_t(fbits), any_big ? 0u : 2u);
+            }
         }
         const uint32_t* ftab = far ? c->d_far.as<uint32_t>() : nullptr;
         {
@@ -307,20 +327,28 @@ int encode_device_locked(mlz_ctx* c, hipStream_t st, int level, const uint8_t* d
             {
                 Timer t(c, T_ENC_TILES, st);
                 const uint32_t grid = ((tiles + 7) / 8) * 8;  // whole rounds of the eight XCDs (see the kernel's workgroup -> tile map)
-#define MLZ_LAUNCH_M2(F, HB, CLS)                                                                                                            \
-    hipLaunchKernelGGL((match_tiles_kernel<F, MLZ_M2_NW, HB>), dim3(grid), dim3(256), M2Cfg<HB>::kLds, st, d_src, blocks, tile_block,        \
-                       c->d_recs.as<uint2>(), c->d_piece_cnt.as<uint32_t>(), ftab, epochs, pattern, tiles, uint32_t(CLS))
+#define MLZ_LAUNCH_M2(F, HB, CLS, ...)                                                                                                       \
+    hipLaunchKernelGGL((match_tiles_kernel<F, MLZ_M2_NW, HB, ##__VA_ARGS__>), dim3(grid), dim3(256), M2Cfg<HB>::kLds, st, d_src, blocks, tile_block,        \
+                       c->d_recs.as<uint2>(), c->d_piece_cnt.as<uint32_t>(), ftab, epochs, pattern, tiles, uint32_t(CLS), uint32_t(fbits))
                 if (level == MLZ_LEVEL_SUPERFAST) MLZ_LAUNCH_M2(false, kM2HashBitsSuperFast, 2);
-                else if (l2new && far)
-                    hipLaunchKernelGGL((match_tiles_kernel<true, MLZ_M2_NW, kM2HashBitsSmall, kL2FarBits, true>), dim3(grid), dim3(256), M2Cfg<kM2HashBitsSmall>::kLds, st,
-                                       d_src, blocks, tile_block, c->d_recs.as<uint2>(), c->d_piece_cnt.as<uint32_t>(), ftab, epochs, pattern, tiles, 2u);
+                else if (l2new && far) {
+                    // the same kernel for both block classes, with far tables of the level's size or of the block's
+                    if (any_big)
+                        hipLaunchKernelGGL((match_tiles_kernel<true, MLZ_M2_NW, kM2HashBitsSmall, kL2FarBits, true>), dim3(grid), dim3(256), M2Cfg<kM2HashBitsSmall>::kLds,
+                                           st, d_src, blocks, tile_block, c->d_recs.as<uint2>(), c->d_piece_cnt.as<uint32_t>(), ftab, epochs, pattern, tiles,
+                                           any_small ? 1u : 2u, uint32_t(fbits));
+                    if (any_small)
+                        hipLaunchKernelGGL((match_tiles_kernel<true, MLZ_M2_NW, kM2HashBitsSmall, 0, true>), dim3(grid), dim3(256), M2Cfg<kM2HashBitsSmall>::kLds, st,
+                                           d_src, blocks, tile_block, c->d_recs.as<uint2>(), c->d_piece_cnt.as<uint32_t>(), ftab, epochs, pattern, tiles,
+                                           any_big ? 0u : 2u, uint32_t(fbits));
+                }
                 else if (l2new)   // blocks of one tile: no far tables, but the same near-table seeding as the level's other blocks
                     hipLaunchKernelGGL((match_tiles_kernel<false, MLZ_M2_NW, kM2HashBitsSmall, kL2FarBits, true>), dim3(grid), dim3(256), M2Cfg<kM2HashBitsSmall>::kLds, st,
-                                       d_src, blocks, tile_block, c->d_recs.as<uint2>(), c->d_piece_cnt.as<uint32_t>(), ftab, epochs, pattern, tiles, 2u);
+                                       d_src, blocks, tile_block, c->d_recs.as<uint2>(), c->d_piece_cnt.as<uint32_t>(), ftab, epochs, pattern, tiles, 2u, uint32_t(fbits));
                 else {
                     // one launch per block class that occurs in the batch (usually one)
                     if (any_big) { if (far) MLZ_LAUNCH_M2(true, kM2HashBitsBig, any_small ? 1 : 2); else MLZ_LAUNCH_M2(false, kM2HashBitsBig, any_small ? 1 : 2); }
-                    if (any_small) { if (far) MLZ_LAUNCH_M2(true, kM2HashBitsSmall, any_big ? 0 : 2); else MLZ_LAUNCH_M2(false, kM2HashBitsSmall, any_big ? 0 : 2); }
+                    if (any_small) { if (far) MLZ_LAUNCH_M2(true, kM2HashBitsSmall, any_big ? 0 : 2, 0); else MLZ_LAUNCH_M2(false, kM2HashBitsSmall, any_big ? 0 : 2); }
                 }
 #undef MLZ_LAUNCH_M2
             }

@@ -1,6 +1,6 @@
 """The device encoder against its CPU model (tools/encmodel2: a sequential statement of exactly the match + serialize
 kernels' algorithm, test infrastructure like the oracle): block bodies must be byte-identical at LevelFastest and
-LevelBalanced, for both block classes (>= 1 MiB: 12-bit near tables; smaller: 13-bit)."""
+LevelBalanced, for both block classes (>= 1 MiB: 12-bit near tables; smaller: 13-bit, far tables sized by the block)."""
 import ctypes as C
 import os
 import sys
@@ -41,8 +41,14 @@ def _model_body(run2, a, level):
 def test_device_output_equals_the_model(ctx, model, level):
     rng = np.random.default_rng(9)
     mix = np.concatenate([synth.text_like(200000, 4), rng.integers(0, 256, 100000, dtype=np.uint8), synth.json_like(150000, 5)])
-    cases = [synth.text_like(100000, 7), synth.text_like((1 << 20) + 77, 8), mix, synth.json_like(3 << 20, 2)]
+    cases = [synth.text_like(100000, 7), synth.text_like((1 << 20) + 77, 8), mix, synth.json_like(3 << 20, 2),
+             synth.text_like(64 << 10, 3), synth.text_like((128 << 10) + 5, 6), synth.json_like(300000, 9), synth.text_like(700000, 10)]
+    lv = mz.LevelFastest if level == 1 else mz.LevelBalanced
     for a in cases:
         a = np.ascontiguousarray(a)
-        enc = mz.Encode(a, mz.LevelFastest if level == 1 else mz.LevelBalanced, ctx)
+        enc = mz.Encode(a, lv, ctx)
         assert _body(enc) == _model_body(model, a, level), (level, a.size)
+    # one batch with blocks of every size class (far tables of different sizes side by side)
+    encs = mz.encode_batch([np.ascontiguousarray(a) for a in cases], lv, ctx)
+    for a, enc in zip(cases, encs):
+        assert _body(enc) == _model_body(model, np.ascontiguousarray(a), level), (level, a.size, "batch")

@@ -18,11 +18,20 @@ DEF = dict(sub=4, nw=4, near_bits=12, lazy=3, use_rep=0, far=1, lane_cap=32, bac
 # previous epoch's table probed as well
 DEF_L2 = dict(DEF, near_bits=13, far_prev=1, far_bits=18, far_stride=2, seed_stride=1)
 
+def small_far_bits(nbytes, shift=2):
+    """mlz_encode.hip.inc small_far_bits: far-table entries (log2) of a LevelFastest block below 1 MiB."""
+    lg = 14 + shift
+    while lg < 17 + shift and (1 << lg) < nbytes:
+        lg += 1
+    return lg - shift
+
 def def_for(nbytes, level=1):
     """The kernels' configuration for a block of nbytes (mlz_encode2.hip.inc: kM2BigBlock)."""
     if level == 2:
-        return dict(DEF_L2)
-    return dict(DEF, near_bits=12 if nbytes >= (1 << 20) else 13)
+        return dict(DEF_L2) if nbytes >= (1 << 20) else dict(DEF_L2, far_bits=small_far_bits(nbytes) + 1)
+    if nbytes >= (1 << 20):
+        return dict(DEF)
+    return dict(DEF, near_bits=13, far_bits=small_far_bits(nbytes))
 
 def run(data, check=True, block=8 << 20, **kw):
     d = dict(DEF); d.update(kw); p = P(**d)

@@ -18,7 +18,8 @@ time).  cpu_baseline = the CPU oracle (a C restatement of the reference's pure-G
 reference's AMD64 asm) on this box's cores: threads started and buffers touched before the clock, a sweep over
 thread counts with the best one reported, and the single-thread rate.  On rank 0 of a 1-GPU run the line also
 carries: config.decode_foreign_MBps (the same stream encoded by the reference's algorithm — every such stream
-takes the decoder's general path), config.end_to_end_MBps (pinned host memory -> mlz_encode_batch /
+takes the decoder's general path; decode_foreign_2MiB_blocks_MBps: the same in blocks of the reference Writer's
+default size), config.end_to_end_MBps (pinned host memory -> mlz_encode_batch /
 mlz_decode_batch -> pinned host memory, PCIe included; never the headline value).
 """
 import argparse
@@ -431,6 +432,33 @@ def main():
         torch.cuda.synchronize(dev)
         extras["decode_foreign_MBps"] = round(S / 1e6 / ((time.perf_counter() - t0) / 10), 1)
         extras["decode_foreign_ratio"] = round(sum(lens) / S, 4)
+        # ... and cut into blocks of the reference Writer's default size (2 MiB, minlz.go:106): what a .mz file made with
+        # default options holds
+        from minlz_amd._lib import BlockDesc
+        FB = 2 << 20
+        fn = (S + FB - 1) // FB
+        fstride = FB + 256
+        fenc = np.zeros(fn * fstride, dtype=np.uint8)
+        fl = []
+        for i in range(fn):
+            e = O.encode(host[i * FB:min(S, (i + 1) * FB)], 1)
+            fenc[i * fstride:i * fstride + len(e)] = np.frombuffer(e, dtype=np.uint8)
+            fl.append(len(e))
+        d_fenc = torch.from_numpy(fenc).to(dev)
+        fdesc = (BlockDesc * fn)(*[BlockDesc(i * fstride, fl[i], i * FB, min(FB, S - i * FB)) for i in range(fn)])
+        d_flen = torch.zeros(fn, dtype=torch.int64, device=dev)
+        fst = torch.cuda.current_stream(dev).cuda_stream
+        main_leg.dec.zero_()
+        for _ in range(3):
+            ctx.decode_batch_device(fst, d_fenc.data_ptr(), main_leg.dec.data_ptr(), fdesc, d_flen.data_ptr())
+        torch.cuda.synchronize(dev)
+        assert torch.equal(main_leg.dec[:S], main_leg.src), "decode of the reference-algorithm stream (2 MiB blocks) failed"
+        t0 = time.perf_counter()
+        for _ in range(10):
+            ctx.decode_batch_device(fst, d_fenc.data_ptr(), main_leg.dec.data_ptr(), fdesc, d_flen.data_ptr())
+        torch.cuda.synchronize(dev)
+        extras["decode_foreign_2MiB_blocks_MBps"] = round(S / 1e6 / ((time.perf_counter() - t0) / 10), 1)
+        del d_fenc
         # ---- end to end through the host-pointer ABI, pinned memory on both sides (PCIe included) ----
         from minlz_amd import _lib
         L = _lib.lib()

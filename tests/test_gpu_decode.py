@@ -280,6 +280,12 @@ def test_many_general_blocks_take_the_tile_ordered_phase(ctx):
     encs = [O.encode(b, 1 + (i % 3)) for i, b in enumerate(blocks)]
     assert mz.decode_batch(encs, ctx) == blocks
     assert ctx.general_blocks() >= 20
+    # one long block among many short ones: the choice between the two routes weighs tiles, not blocks (this batch goes through
+    # the jumping rounds: the ordered phase would take as long as the long block has tiles)
+    big = synth.text_like(3 << 20, 29).tobytes()
+    mixed = [O.encode(big, 1)] + encs[:22]
+    assert mz.decode_batch(mixed, ctx) == [big] + blocks[:22]
+    assert ctx.general_blocks() >= 20
     # a stream that lies about a copy (offset beyond the start) in the middle of such a batch: that block fails, the others do not
     bad = bytearray(encs[7])
     body0 = 1 + 3  # header: 00 + uvarint(262144) is 3 bytes

@@ -6,18 +6,21 @@ otherwise (writer.go:876-910); the stream starts with `ff 06 00 00 "MinLz" (log2
 (writer.go:1553-1556) and ends with the EOF chunk `20 len uvarint(total)` (writer.go:1063-1074).
 Blocks are handed to a *backend* in batches — one launch per batch on the GPU instead of one
 goroutine per block (writer.go:501-560, reader.go:830-859).  The seek index (index.py) can be
-appended after the EOF chunk (WriterAddIndex) and drives ReadSeeker; no padding / search tables.
+appended after the EOF chunk (WriterAddIndex) and drives ReadSeeker; WriterPadding pads the closed stream with a
+skippable chunk; Reader.Skip leaves blocks out without decoding them.  No search tables.
 
 Backends: HipBackend (the product: everything on the device through the C ABI).  Tests inject an
 oracle-based backend to exercise this host logic without a GPU.
 """
 import io
+import os
 
 from . import api
 from .index import Index
 
 MAGIC = b"\xff\x06\x00\x00MinLz"
 CHUNK_UNCOMPRESSED, CHUNK_MINLZ, CHUNK_MINLZ_COMPCRC, CHUNK_EOF, CHUNK_STREAM_ID = 0x01, 0x02, 0x03, 0x20, 0xFF
+CHUNK_PADDING = 0xFE   # skippable: "Section 4.4 Padding" (writer.go:1165-1166)
 MIN_BLOCK, MAX_BLOCK, DEFAULT_BLOCK = 4 << 10, 8 << 20, 2 << 20  # minlz.go:98-106
 
 
@@ -69,12 +72,30 @@ class HipBackend:
         return [api.crc(b, self.ctx) for b in blocks]
 
 
+def _calc_skippable_frame(written, multiple):
+    """calcSkippableFrame (writer.go:1135-1151): bytes to add so that written becomes a multiple; never 1..3 (a chunk header is 4)."""
+    left = written % multiple
+    if left == 0:
+        return 0
+    add = multiple - left
+    while add < 4:
+        add += multiple
+    return add
+
+
 class Writer:
     """NewWriter(w, WriterLevel(level), WriterBlockSize(bs), WriterConcurrency(n)) (writer.go:35-86)."""
 
-    def __init__(self, w, level=api.LevelBalanced, block_size=DEFAULT_BLOCK, concurrency=16, backend=None, add_index=False):
+    def __init__(self, w, level=api.LevelBalanced, block_size=DEFAULT_BLOCK, concurrency=16, backend=None, add_index=False,
+                 padding=0, padding_src=None):
         if not (MIN_BLOCK <= block_size <= MAX_BLOCK):
             raise ValueError("minlz: block size must be 4KiB..8MiB")  # writer.go:1238-1246
+        # WriterPadding(n) / WriterPaddingSrc(r) (writer.go:1248-1277): Close pads the output to a multiple of n with a
+        # skippable 0xfe chunk of random bytes (padding_src: a callable n -> bytes; os.urandom by default)
+        if padding < 0 or padding > MAX_BLOCK:
+            raise ValueError("minlz: padding must be 1..8MiB")
+        self.pad = 0 if padding == 1 else padding
+        self.pad_src = padding_src or os.urandom
         if level not in (api.LevelSuperFast, api.LevelUncompressed, api.LevelFastest, api.LevelBalanced):
             raise api.ErrInvalidLevel()
         self.w, self.level, self.block_size, self.batch = w, level, block_size, max(1, concurrency)
@@ -141,7 +162,19 @@ class Writer:
         self._flush_blocks(True)
         v = put_uvarint(self.uncomp_written)
         self._emit(bytes([CHUNK_EOF, len(v), 0, 0]) + v)  # writer.go:1063-1074
-        self.index_bytes = self.index.append_to(self.uncomp_written, self.written)  # writer.go:1080-1088
+        # the index does not record the compressed size of a padded stream (writer.go:1083-1087)
+        self.index_bytes = self.index.append_to(self.uncomp_written, self.written if self.pad <= 1 else -1)
+        if self.pad > 1:
+            # an appended index counts as written before the padding is sized, and follows it (writer.go:1089-1121)
+            total = _calc_skippable_frame(self.written + (len(self.index_bytes) if self.add_index else 0), self.pad)
+            if total:
+                if total >= MAX_BLOCK + 4:
+                    raise ValueError("minlz: requested skippable frame >= max")   # writer.go:1162-1164
+                f = total - 4
+                fill = bytes(self.pad_src(f))
+                if len(fill) != f:
+                    raise ValueError("minlz: short read from the padding source")
+                self._emit(bytes([CHUNK_PADDING, f & 0xFF, (f >> 8) & 0xFF, (f >> 16) & 0xFF]) + fill)
         if self.add_index:
             self._emit(self.index_bytes)
         self.closed = True
@@ -165,6 +198,15 @@ class Reader:
         self.batch = max(1, batch)
         self.backend = backend or HipBackend()
         self.partial = False  # set by ReadSeeker: the input is a fragment cut at chunk boundaries
+        self._skip = 0        # Skip(): uncompressed bytes the next WriteTo / ReadAll leaves out
+
+    def Skip(self, n):
+        """Reader.Skip (reader.go:1034-1302): the next n uncompressed bytes are not delivered.  Blocks that lie entirely inside
+        the skipped range are not decoded (and their CRC is not checked); the block the range ends in is.  Skipping past the
+        end of the stream fails when it is read."""
+        if n < 0:
+            raise ValueError("attempted negative skip")
+        self._skip += n
 
     def _read_full(self, n, allow_eof=False):
         b = self.r.read(n)
@@ -191,8 +233,8 @@ class Reader:
             for p, c in zip(pending, crcs):
                 if c != p[2]:
                     raise api.ErrCRC()
-        for d in res:
-            out.write(d)
+        for p, d in zip(pending, res):
+            out.write(d[p[-1]:] if p[-1] else d)   # (the last field: leading bytes Skip() took)
         pending.clear()
 
     def WriteTo(self, w):
@@ -226,7 +268,11 @@ class Reader:
                 if n == 0 or n < body_len:
                     raise api.ErrCorrupt()  # reader.go:327
                 # type 0x03: the CRC covers the token bytes instead of the decoded ones (reader.go:341-344)
-                pending.append(("c3" if ctype == CHUNK_MINLZ_COMPCRC else "c", buf[4:], crc, buf[4 + hl:]))
+                if self._skip >= n:
+                    self._skip -= n   # skipped completely: not decoded (reader.go:1132-1137)
+                else:
+                    pending.append(("c3" if ctype == CHUNK_MINLZ_COMPCRC else "c", buf[4:], crc, buf[4 + hl:], self._skip))
+                    self._skip = 0
                 stream_out += n
             elif ctype == CHUNK_UNCOMPRESSED:
                 if clen < 4 or clen > api.MaxEncodedLen(max_block) + 4:
@@ -235,7 +281,12 @@ class Reader:
                 n = clen - 4
                 if n > max_block:
                     raise api.ErrTooLarge()
-                pending.append(("u", self._read_full(n), int.from_bytes(crcb, "little")))
+                raw = self._read_full(n)
+                if self._skip >= n:
+                    self._skip -= n
+                else:
+                    pending.append(("u", raw, int.from_bytes(crcb, "little"), None, self._skip))
+                    self._skip = 0
                 stream_out += n
             elif ctype == CHUNK_EOF:
                 if clen > 10:
@@ -272,6 +323,8 @@ class Reader:
             if len(pending) >= self.batch:
                 self._drain(pending, w)
         self._drain(pending, w)
+        if self._skip:
+            raise api.ErrCorrupt("unexpected EOF")   # io.ErrUnexpectedEOF (reader.go:1060-1064)
         return None
 
     DecodeConcurrent = WriteTo

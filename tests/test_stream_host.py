@@ -86,3 +86,81 @@ def test_writer_option_errors():
         S.Writer(io.BytesIO(), block_size=1024, backend=OracleBackend())
     with pytest.raises(api.ErrInvalidLevel):
         S.Writer(io.BytesIO(), level=9, backend=OracleBackend())
+
+
+def test_writer_padding():
+    # WriterPadding (writer.go:1248-1268, :1094-1112): the closed stream is a multiple of n, the filler is a skippable 0xfe chunk
+    # that no reader sees, and an appended index still ends the stream
+    d = synth.text_like(200000, 3).tobytes()
+    plain = enc(d, 1, 65536)
+    for n in (2, 7, 512, 4096, 1 << 20):
+        for add_index in (False, True):
+            w = io.BytesIO()
+            wr = S.Writer(w, level=1, block_size=65536, concurrency=3, backend=OracleBackend(), add_index=add_index, padding=n,
+                          padding_src=lambda k: bytes([0xA5]) * k)
+            wr.EncodeBuffer(d)
+            wr.Close()
+            s = w.getvalue()
+            assert len(s) % n == 0 and wr.Written() == len(s), (n, add_index)
+            assert s[:len(plain)] == plain                      # the stream itself is unchanged
+            rest = s[len(plain):]
+            if rest and rest[0] == 0xFE:
+                f = rest[1] | rest[2] << 8 | rest[3] << 16
+                assert rest[4:4 + f] == bytes([0xA5]) * f and f + 4 >= 4
+                rest = rest[4 + f:]
+            assert (len(rest) > 0) == add_index                 # what follows the padding is the index
+            assert S.Reader(s, backend=OracleBackend()).ReadAll() == d
+            assert O.stream_decode(s, len(d)) == d
+            if add_index:
+                rs = S.ReadSeeker(s, backend=OracleBackend())
+                rs.Seek(150000)
+                assert rs.Read(1000) == d[150000:151000]
+    # calcSkippableFrame (writer.go:1135-1151): nothing to add on a multiple, never a frame shorter than its header
+    assert S._calc_skippable_frame(4096, 4096) == 0 and S._calc_skippable_frame(4095, 4096) == 4097 and S._calc_skippable_frame(10, 16) == 6
+    # padding 1 = off (writer.go:1259-1262); random filler by default
+    w = io.BytesIO()
+    wr = S.Writer(w, level=1, block_size=65536, backend=OracleBackend(), padding=1)
+    wr.EncodeBuffer(d); wr.Close()
+    assert w.getvalue() == plain
+    w = io.BytesIO()
+    wr = S.Writer(w, level=1, block_size=65536, backend=OracleBackend(), padding=1000)
+    wr.EncodeBuffer(d); wr.Close()
+    assert len(w.getvalue()) % 1000 == 0 and S.Reader(w.getvalue(), backend=OracleBackend()).ReadAll() == d
+
+
+class CountingBackend(OracleBackend):
+    def __init__(self):
+        self.decoded = 0
+
+    def decode_bodies(self, bodies):
+        self.decoded += len(bodies)
+        return super().decode_bodies(bodies)
+
+
+def test_reader_skip():
+    # Reader.Skip (reader.go:1034-1302): whole blocks inside the skipped range are neither decoded nor CRC-checked, the
+    # block the range ends in is; skipping past the end is an unexpected EOF
+    bs = 4096
+    d = synth.text_like(10 * bs + 123, 5).tobytes() + synth.random_bytes(2 * bs).tobytes()   # compressed and stored chunks
+    s = enc(d, 1, bs)
+    for n in (0, 1, bs - 1, bs, bs + 1, 3 * bs, 7 * bs + 5, len(d) - 1, len(d)):
+        be = CountingBackend()
+        r = S.Reader(s, backend=be)
+        r.Skip(n)
+        assert r.ReadAll() == d[n:], n
+        assert be.decoded <= 11 - min(n // bs, 11), (n, be.decoded)   # 11 compressed blocks, the skipped ones untouched
+    r = S.Reader(s, backend=OracleBackend())
+    r.Skip(2 * bs); r.Skip(bs + 7)                                        # skips add up
+    assert r.ReadAll() == d[3 * bs + 7:]
+    with pytest.raises(api.ErrCorrupt):
+        r = S.Reader(s, backend=OracleBackend()); r.Skip(len(d) + 1); r.ReadAll()
+    with pytest.raises(ValueError):
+        S.Reader(s, backend=OracleBackend()).Skip(-1)
+    # a damaged block: invisible when skipped, an error when read
+    bad = bytearray(s)
+    first_chunk = 10            # stream header is 10 bytes; the first chunk's CRC follows its 4-byte header
+    bad[first_chunk + 4] ^= 0xFF
+    r = S.Reader(bytes(bad), backend=OracleBackend()); r.Skip(bs)
+    assert r.ReadAll() == d[bs:]
+    with pytest.raises(api.ErrCRC):
+        S.Reader(bytes(bad), backend=OracleBackend()).ReadAll()

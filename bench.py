@@ -151,22 +151,58 @@ def stream_mode(args, ctx, mz, synth, dist, dev, rank, world):
     kern = dict(ctx.timers())
     ctx.set_option(mz.OPT_TIMING, 0)
     k_ms = sum(v for k, v in kern.items() if k.startswith("enc_") or k == "crc")
-    per_rank = [k_ms]
+    # ---- the Reader side (reader.go:575-992): the stream just written, decoded by all ranks ----
+    # Every rank holds the .mz stream in host memory (a file all ranks can read): chunk walk, upload of ITS span over its own
+    # PCIe link, device decode + CRC check, output left sharded in HBM (shard.decode_stream_sharded_device).  PCIe-inclusive
+    # by construction (the Reader's input is host bytes), so this is reported beside the encode rate, not as `value`.
+    box = [out.cpu().numpy().tobytes() if rank == 0 else None]
     if dist is not None:
-        tt = torch.tensor([elapsed, k_ms], dtype=torch.float64, device=dev)
+        dist.broadcast_object_list(box, src=0)
+    sbytes = torch.empty(len(box[0]), dtype=torch.uint8, pin_memory=True)
+    sbytes.numpy()[:] = np.frombuffer(box[0], dtype=np.uint8)
+
+    def dstep():
+        return shard.decode_stream_sharded_device(codec, sbytes, rank, world, dev)
+    local, (ulo, uhi), dtotal = dstep()
+    torch.cuda.synchronize(dev)
+    assert dtotal == total and (ulo, uhi) == (lo, hi) and torch.equal(local, src), "sharded stream decode mismatch"
+    ctx.set_option(mz.OPT_TIMING, 2)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        dstep()
+    torch.cuda.synchronize(dev)
+    if dist is not None:
+        dist.barrier()
+    d_elapsed = time.perf_counter() - t0
+    dkern = dict(ctx.timers())
+    ctx.set_option(mz.OPT_TIMING, 0)
+    dk_ms = sum(v for k, v in dkern.items() if k.startswith("dec_") or k == "crc")
+    per_rank, dper_rank = [k_ms], [dk_ms]
+    if dist is not None:
+        tt = torch.tensor([elapsed, k_ms, d_elapsed, dk_ms], dtype=torch.float64, device=dev)
         allt = [torch.zeros_like(tt) for _ in range(world)]
         dist.all_gather(allt, tt)
         elapsed = max(float(t[0]) for t in allt)
         per_rank = [round(float(t[1]), 4) for t in allt]
+        d_elapsed = max(float(t[2]) for t in allt)
+        dper_rank = [round(float(t[3]), 4) for t in allt]
     if rank == 0:
         ms = elapsed / args.steps * 1e3
+        dms = d_elapsed / args.steps * 1e3
         print(json.dumps({"metric": "MB/s stream encode, 8MB blocks, one stream over N GPUs", "value": round(total / 1e6 / (elapsed / args.steps), 1), "unit": "MB/s",
                           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 4), "higher_is_better": True,
                           "scaling": "strong", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
                           "config": {"workload": "%s stream of %d B in 8 MiB blocks, level %d, contiguous block ranges per rank, framed chunks (CRC32C on the device) "
                                                  "gathered in order into rank 0's HBM" % (args.workload, total, args.level),
                                      "stream_bytes": clen, "ratio": round(clen / max(total, 1), 4), "kernel_ms_per_rank": per_rank,
-                                     "outside_kernels_ms": round(ms - max(per_rank), 4), "device": ctx.device_name()}}), flush=True)
+                                     "outside_kernels_ms": round(ms - max(per_rank), 4),
+                                     "reader": {"what": "the same stream from host memory on every rank: chunk walk, H2D of the rank's span, device decode + CRC check, output left sharded",
+                                                "decode_MBps": round(total / 1e6 / (d_elapsed / args.steps), 1), "ms_per_step": round(dms, 4),
+                                                "kernel_ms_per_rank": dper_rank, "outside_kernels_ms": round(dms - max(dper_rank), 4)},
+                                     "ranks_rccl": dist.get_world_size() if dist is not None else 1, "device": ctx.device_name()}}), flush=True)
     if dist is not None:
         dist.destroy_process_group()
 
@@ -189,9 +225,23 @@ def main():
     ap.add_argument("--file", default=os.environ.get("MINLZ_BENCH_FILE"), help="real input (e.g. enwik8); every rank reads its own --bytes slice, wrapping around")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start the N ranks here (one process per GPU, the same command the
+        # driver uses) and pass rank 0's JSON line through.  Fails loudly when the box has fewer than N GPUs.
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            sys.exit("bench.py --gpus %d: only %d GPU(s) visible on this box — not running a smaller world under the same label" % (args.gpus, have))
+        import socket
+        sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        sys.exit(subprocess.call(cmd, env=env))
+
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, "bench.py --gpus %d was started with WORLD_SIZE=%d: the line would misreport n_gpus" % (args.gpus, world)
     if world > 1 or os.environ.get("MINLZ_BENCH_FORCE_DIST"):   # (the env switch runs the N > 1 code path with one rank: a smoke test)
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -199,6 +249,7 @@ def main():
         os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         torch.cuda.set_device(local)
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+        assert dist.get_world_size() == args.gpus, (dist.get_world_size(), args.gpus)   # the ranks RCCL saw
     else:
         dist = None
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback exists for the product path)"
@@ -236,29 +287,43 @@ def main():
 
     class Leg:
         """HBM-resident encode + decode of one stream through the device-resident batch calls."""
-        def __init__(self, data):
-            self.host = data
-            self.S = data.size
-            self.nblk = (self.S + BLOCK - 1) // BLOCK
-            self.src = torch.from_numpy(data).to(dev)
-            self.stride = BLOCK + 256
+        def __init__(self, data, level=None, block=BLOCK):
+            """data: numpy uint8 (uploaded) or a uint8 tensor already on the device."""
+            self.level = args.level if level is None else level
+            self.block = block
+            self.src = data if isinstance(data, torch.Tensor) else torch.from_numpy(data).to(dev)
+            self.host = None if isinstance(data, torch.Tensor) else data
+            self.S = int(self.src.numel())
+            self.nblk = (self.S + block - 1) // block
+            self.stride = block + 256
             self.enc = torch.empty(self.nblk * self.stride, dtype=torch.uint8, device=dev)
             self.dec = torch.empty(self.S + 256, dtype=torch.uint8, device=dev)
             self.enc_len = torch.zeros(self.nblk, dtype=torch.int64, device=dev)
             self.dec_len = torch.zeros(self.nblk, dtype=torch.int64, device=dev)
-            self.blk_len = [min(BLOCK, self.S - i * BLOCK) for i in range(self.nblk)]
-            self.e_desc = (BlockDesc * self.nblk)(*[BlockDesc(i * BLOCK, self.blk_len[i], i * self.stride, self.stride) for i in range(self.nblk)])
+            self.blk_len = [min(block, self.S - i * block) for i in range(self.nblk)]
+            self.e_desc = (BlockDesc * self.nblk)(*[BlockDesc(i * block, self.blk_len[i], i * self.stride, self.stride) for i in range(self.nblk)])
             self.d_desc = None
             self.clens = None
 
         def run_encode(self):
-            ctx.encode_batch_device(stream, args.level, self.src.data_ptr(), self.enc.data_ptr(), self.e_desc, self.enc_len.data_ptr())
+            ctx.encode_batch_device(stream, self.level, self.src.data_ptr(), self.enc.data_ptr(), self.e_desc, self.enc_len.data_ptr())
 
         def make_decode_desc(self, lens=None):
             lens = lens if lens is not None else self.enc_len.cpu().tolist()
             assert all(l > 0 for l in lens), lens
-            self.d_desc = (BlockDesc * self.nblk)(*[BlockDesc(i * self.stride, lens[i], i * BLOCK, self.blk_len[i]) for i in range(self.nblk)])
+            self.d_desc = (BlockDesc * self.nblk)(*[BlockDesc(i * self.stride, lens[i], i * self.block, self.blk_len[i]) for i in range(self.nblk)])
             self.clens = lens
+
+        def summary(self, steps, warmup=2):
+            """check + timed -> the fields a config leg reports."""
+            self.check()
+            el, kk = self.timed(steps, warmup)
+            e_ms = sum(v for k, v in kk.items() if k.startswith("enc_")); d_ms = sum(v for k, v in kk.items() if k.startswith("dec_"))
+            return {"bytes": self.S, "blocks": self.nblk, "block_size": self.block, "level": self.level,
+                    "value_MBps": round(self.S / 1e6 / (el / steps), 1), "ratio": round(sum(self.clens) / self.S, 4),
+                    "encode_MBps": round(self.S / 1e6 / (e_ms / 1e3), 1) if e_ms else None,
+                    "decode_MBps": round(self.S / 1e6 / (d_ms / 1e3), 1) if d_ms else None,
+                    "kernel_ms": {k: round(v, 4) for k, v in kk.items()}}
 
         def run_decode(self):
             ctx.decode_batch_device(stream, self.enc.data_ptr(), self.dec.data_ptr(), self.d_desc, self.dec_len.data_ptr())
@@ -487,15 +552,75 @@ def main():
                                      "note": "pinned host -> mlz_encode_batch / mlz_decode_batch -> pinned host, copies overlapped with kernels in 32 MiB groups"}
         del psrc, penc, pdec
         # ---- the round-1 stand-in, for continuity with BENCH_r01 ----
-        if args.workload == "enwik" and not args.file:
+        if args.workload == "enwik" and not args.file and args.level == 1:
             leg = Leg(synth.text_like(S, seed=1))
-            leg.check()
-            el, kk = leg.timed(max(3, args.steps // 2), 2)
-            e_ms = sum(v for k, v in kk.items() if k.startswith("enc_")); d_ms = sum(v for k, v in kk.items() if k.startswith("dec_"))
-            extras["r01_standin"] = {"workload": "synth.text_like (the round-1 bench stream)", "value_MBps": round(leg.S / 1e6 / (el / max(3, args.steps // 2)), 1),
-                                     "ratio": round(sum(leg.clens) / leg.S, 4), "encode_MBps": round(leg.S / 1e6 / (e_ms / 1e3), 1),
-                                     "decode_MBps": round(leg.S / 1e6 / (d_ms / 1e3), 1), "kernel_ms": {k: round(v, 4) for k, v in kk.items()}}
+            r = leg.summary(max(3, args.steps // 2))
+            r["workload"] = "synth.text_like (the round-1 bench stream)"
+            extras["r01_standin"] = r
             del leg
+        # ---- BASELINE configs 3, 4, 5 at single-GPU scale, and the smallest stream block sizes (short legs) ----
+        if args.workload == "enwik" and not args.file and args.level == 1:
+            nth = usable_cpus()
+            # config 3: JSON-like stream, LevelBalanced, 8 MiB blocks (the 8-GPU form of it is --mode stream)
+            jd = synth.json_like(S, seed=77)
+            leg = Leg(jd, level=2)
+            r = leg.summary(5)
+            _, cb2 = O.bench_encode(jd, BLOCK, 2, nth, 1)
+            r["workload"] = "synth.json_like, LevelBalanced (BASELINE config 3 on one GPU)"
+            r["oracle_L2_ratio"] = round(cb2 / jd.size, 4)
+            r["ratio_vs_oracle_L2"] = round(r["ratio"] / (cb2 / jd.size), 4)
+            extras["config3_json_L2"] = r
+            del leg, jd
+            # config 4: 1 GiB of incompressible bytes: every block must take the stored path (00 00 raw)
+            g = torch.Generator(device=dev); g.manual_seed(4)
+            rnd = torch.randint(0, 256, (1 << 30,), dtype=torch.uint8, device=dev, generator=g)
+            leg = Leg(rnd, level=1)
+            r = leg.summary(3, warmup=1)
+            assert all(c == b + 2 for c, b in zip(leg.clens, leg.blk_len)), "incompressible blocks were not stored"
+            r["workload"] = "1 GiB of PRNG bytes (BASELINE config 4): all 128 blocks stored, N read + N written per direction"
+            r["stored_blocks"] = leg.nblk
+            extras["config4_incompressible_1GiB"] = r
+            del leg, rnd
+            # config 5: 64 KiB blocks encoded at LevelSmallest by the reference's algorithm on the CPU; device decode only
+            td = synth.text_like(512 * 65536, seed=12)
+            encs = [O.encode(td[i:i + 65536], 3) for i in range(0, td.size, 65536)]
+            reps = 8
+            st5 = 65536 + 256
+            h5 = np.zeros(len(encs) * st5, dtype=np.uint8)
+            for i, e in enumerate(encs):
+                h5[i * st5:i * st5 + len(e)] = np.frombuffer(e, dtype=np.uint8)
+            d5 = torch.from_numpy(h5).to(dev).repeat(reps)
+            n5 = len(encs) * reps
+            desc5 = (BlockDesc * n5)(*[BlockDesc(i * st5, len(encs[i % len(encs)]), i * 65536, 65536) for i in range(n5)])
+            out5 = torch.empty(n5 * 65536 + 256, dtype=torch.uint8, device=dev)
+            len5 = torch.zeros(n5, dtype=torch.int64, device=dev)
+            ctx.decode_batch_device(stream, d5.data_ptr(), out5.data_ptr(), desc5, len5.data_ptr())
+            torch.cuda.synchronize(dev)
+            ref5 = torch.from_numpy(td).to(dev)
+            assert bool((len5 == 65536).all()) and all(torch.equal(out5[k * td.size:(k + 1) * td.size], ref5) for k in (0, reps - 1)), "config-5 decode mismatch"
+            ctx.set_option(12, 0xffffffff); ctx.set_option(mz.OPT_TIMING, 2)
+            t0 = time.perf_counter()
+            for _ in range(5):
+                ctx.decode_batch_device(stream, d5.data_ptr(), out5.data_ptr(), desc5, len5.data_ptr())
+            torch.cuda.synchronize(dev)
+            t5 = (time.perf_counter() - t0) / 5
+            k5 = dict(ctx.timers()); ctx.set_option(mz.OPT_TIMING, 0)
+            extras["config5_L3_64KiB_decode"] = {"workload": "%d x 64 KiB blocks (512 distinct text blocks x %d) encoded by the oracle's LevelSmallest (encode_l3.go restatement) on the CPU; "
+                                                             "device decode only (BASELINE config 5)" % (n5, reps),
+                                                 "blocks": n5, "decode_MBps": round(n5 * 65536 / 1e6 / t5, 1), "ratio_L3": round(sum(len(e) for e in encs) / td.size, 4),
+                                                 "general_blocks": ctx.general_blocks(),
+                                                 "kernel_ms": {k: round(v, 4) for k, v in k5.items() if k.startswith("dec_")}}
+            del d5, out5, ref5
+            # the smallest stream block sizes (writer.go:1238-1246): encode + decode of the bench stream in 4 KiB and 16 KiB blocks
+            sm = {}
+            for bs in (4096, 16384):
+                leg = Leg(host[:64 << 20], level=1, block=bs)
+                r = leg.summary(3, warmup=1)
+                _, cbs = O.bench_encode(host[:16 << 20], bs, 1, nth, 1)
+                r["oracle_L1_ratio_same_blocks"] = round(cbs / (16 << 20), 4)
+                sm["%dKiB" % (bs >> 10)] = r
+                del leg
+            extras["small_stream_blocks"] = sm
 
     cpu = None
     if not args.no_cpu and world == 1:   # the CPU leg runs on rank 0 of the single-GPU run only
@@ -508,12 +633,13 @@ def main():
            "decode_MBps": round(S / 1e6 / (dec_ms / 1e3), 1) if dec_ms else None,
            "kernel_ms": {k: round(v, 4) for k, v in kavg.items()},
            "hbm_read_frac_north_star": round((S / 1e9 / ((enc_ms + dec_ms) / 1e3)) / HBM_PEAK_GBS, 5) if enc_ms + dec_ms else None,
+           "ranks_rccl": dist.get_world_size() if dist is not None else 1,
            "device": ctx.device_name()}
     cfg.update(extras)
     if gather_info:
         cfg["gather"] = gather_info
     out = {
-        "metric": "MB/s encode+decode, 8MB blocks L1",
+        "metric": "MB/s encode+decode, 8MB blocks %s" % {1: "L1", 2: "L2 (LevelBalanced)", -1: "L0 (LevelSuperFast)", 0: "uncompressed"}.get(args.level, "level %d" % args.level),
         "value": round(value, 1),
         "unit": "MB/s",
         "n_gpus": world,

@@ -777,7 +777,12 @@ int mlz_decode_block(mlz_ctx* c, const uint8_t* src, size_t clen, uint8_t* dst, 
     SingleReq rq{false, false, true, 0, src, clen, dst, n, n};
     submit_single(c, rq);
     if (rq.rc) return rq.rc;
-    return rq.out == int64_t(n) ? 0 : 1;
+    if (rq.out == int64_t(n)) return 0;
+    // Per-block failures that are NOT a verdict on the input (a device failure such as a bounded grid barrier giving up:
+    // -MLZ_ERR_HIP; a block the device declines) are passed on as < 0, so that the caller's shim falls back to its CPU
+    // decoder (go/minlz_hip.go: r < 0) instead of reporting a valid stream as corrupt; everything else is "corrupt" = 1.
+    if (rq.out < 0 && rq.out != -MLZ_ERR_CORRUPT) return int(rq.out);
+    return 1;
 }
 
 int mlz_encode_batch(mlz_ctx* c, int level, int n, const uint8_t* const* src, const size_t* src_len, uint8_t* const* dst, const size_t* dst_cap,

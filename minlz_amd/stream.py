@@ -335,6 +335,100 @@ class Reader:
         return out.getvalue()
 
 
+class Chunk:
+    """One data block found by walk_chunks: where its chunk and payload sit in the stream, what it decodes to."""
+    __slots__ = ("kind", "chunk_off", "payload_off", "payload_len", "hdr_len", "n", "crc", "u_off")
+
+    def __init__(self, kind, chunk_off, payload_off, payload_len, hdr_len, n, crc, u_off):
+        self.kind, self.chunk_off, self.payload_off, self.payload_len = kind, chunk_off, payload_off, payload_len
+        self.hdr_len, self.n, self.crc, self.u_off = hdr_len, n, crc, u_off
+
+
+def walk_chunks(buf, max_block_size=MAX_BLOCK):
+    """The chunk walk of Reader.Read / DecodeConcurrent (reader.go:248-543, :575-700) over a whole stream held in memory,
+    WITHOUT decoding: -> (list of Chunk in stream order, total decoded bytes).  Same checks and errors as Reader.WriteTo
+    (stream identifier, chunk length limits, uvarint(N) of 0x02 / 0x03 chunks, EOF length), so a sharded Reader can deal the
+    blocks to its workers knowing every block's output offset.  payload = the chunk body behind the CRC: `uvarint(N) tokens`
+    (hdr_len = the uvarint's bytes) or the raw bytes of a 0x01 chunk."""
+    mv = memoryview(buf).cast("B") if not isinstance(buf, memoryview) else buf
+    size = len(mv)
+    max_block = max_block_size
+    read_header = want_eof = False
+    blocks, pos, stream_out, total = [], 0, 0, 0
+    while True:
+        if pos == size:
+            if want_eof:
+                raise api.ErrCorrupt("unexpected EOF")
+            break
+        if pos + 4 > size:
+            raise api.ErrCorrupt("unexpected EOF")
+        ctype = mv[pos]
+        clen = mv[pos + 1] | mv[pos + 2] << 8 | mv[pos + 3] << 16
+        chunk_off = pos
+        pos += 4
+        if not read_header:
+            if ctype == CHUNK_STREAM_ID:
+                read_header = True
+            elif ctype <= 0x3F and ctype != CHUNK_EOF:
+                raise api.ErrCorrupt("no stream header")
+        # (availability is checked where the Reader would read: after the checks that need only the header)
+        short = pos + clen > size
+        if ctype in (CHUNK_MINLZ, CHUNK_MINLZ_COMPCRC):
+            if clen < 4 or clen > api.MaxEncodedLen(max_block) + 4 or short:
+                raise api.ErrCorrupt()
+            crc = int.from_bytes(mv[pos:pos + 4], "little")
+            n, hl = uvarint(mv[pos + 4:pos + min(clen, 16)])
+            if hl <= 0 or n > 0xFFFFFFFF:
+                raise api.ErrCorrupt()
+            if n > max_block:
+                raise api.ErrTooLarge()
+            if n == 0 or n < clen - 4 - hl:
+                raise api.ErrCorrupt()
+            blocks.append(Chunk(ctype, chunk_off, pos + 4, clen - 4, hl, n, crc, total))
+            stream_out += n; total += n
+        elif ctype == CHUNK_UNCOMPRESSED:
+            if clen < 4 or clen > api.MaxEncodedLen(max_block) + 4 or pos + 4 > size:
+                raise api.ErrCorrupt()
+            n = clen - 4
+            if n > max_block:
+                raise api.ErrTooLarge()
+            if short:
+                raise api.ErrCorrupt("unexpected EOF")
+            blocks.append(Chunk(ctype, chunk_off, pos + 4, n, 0, n, int.from_bytes(mv[pos:pos + 4], "little"), total))
+            stream_out += n; total += n
+        elif ctype == CHUNK_EOF:
+            if clen > 10 or short:
+                raise api.ErrCorrupt()
+            if clen:
+                want, vn = uvarint(mv[pos:pos + clen])
+                if vn != clen or want != stream_out:
+                    raise api.ErrCorrupt("EOF length mismatch")
+            want_eof = read_header = False
+        elif ctype == CHUNK_STREAM_ID:
+            if clen != 6 or short:
+                raise api.ErrCorrupt()
+            if bytes(mv[pos:pos + 5]) != b"MinLz":
+                raise api.ErrUnsupported("not a MinLZ stream")
+            if mv[pos + 5] & 0xC0:
+                raise api.ErrCorrupt()
+            lg = (mv[pos + 5] & 15) + 10
+            if lg > 23:
+                raise api.ErrCorrupt()
+            max_block = 1 << lg
+            if max_block > max_block_size:
+                raise api.ErrTooLarge()
+            stream_out = 0
+            want_eof = True
+        elif ctype == 0x00:
+            raise api.ErrUnsupported("legacy S2/Snappy chunk")
+        elif ctype <= 0x3F:
+            raise api.ErrUnsupported("reserved unskippable chunk")
+        elif short:
+            raise api.ErrCorrupt("unexpected EOF")   # skippable chunk cut short
+        pos += clen
+    return blocks, total
+
+
 class ReadSeeker:
     """Reader.ReadSeeker(index) (reader.go:1304-1487): random access into a stream held in memory.
 

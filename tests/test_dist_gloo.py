@@ -33,7 +33,8 @@ def _worker(rank, world, port, q):
         # device-resident path (CPU tensors here): contiguous block ranges, chunk runs framed per rank, payload gather with
         # isend / irecv into the root's buffer at the final offsets; byte-identical to the reference-shaped stream
         import torch
-        codec = shard.OracleTensorCodec()
+        from tests.oracle_codec import OracleTensorCodec
+        codec = OracleTensorCodec()
         for data, bs in ((synth.text_like(700001, 5).tobytes(), 65536), (synth.random_bytes(300000).tobytes(), 65536), (b"", 4096),
                          (synth.text_like(5000, 6).tobytes(), 4096), (synth.json_like(2_500_000).tobytes(), 1 << 20)):
             n_blocks = (len(data) + bs - 1) // bs
@@ -45,8 +46,37 @@ def _worker(rank, world, port, q):
                 sb = out.numpy().tobytes()
                 results.append(sb == O.stream_encode(data, 1, bs) and O.stream_decode(sb, len(data)) == data)
         results.append(shard.range_of(0, 3, 7) == (0, 3) and shard.range_of(1, 3, 7) == (3, 5) and shard.range_of(2, 3, 7) == (5, 7))
-        if rank == 0:
-            q.put(results)
+        # Reader side (reader.go:575-992): ONE stream made by the oracle's Writer, its blocks decoded by two ranks; output left
+        # sharded (each rank's range checked against the source), gathered into rank 0, and with the stream on rank 0 only
+        from minlz_amd import api
+        for data, bs, lvl in ((synth.text_like(700001, 5).tobytes(), 65536, 1), (synth.random_bytes(300000).tobytes(), 65536, 1), (b"", 4096, 1),
+                              (synth.text_like(5000, 6).tobytes(), 4096, 2), (synth.json_like(2_500_000).tobytes(), 1 << 20, 3),
+                              (synth.text_like(70000, 9).tobytes(), 65536, 1)):
+            sb = O.stream_encode(data, lvl, bs, add_index=(bs == 65536))
+            local, (lo, hi), total = shard.decode_stream_sharded_device(codec, sb, rank, world, "cpu")
+            ok = total == len(data) and local.numpy().tobytes() == data[lo:hi]
+            whole, rng_, _ = shard.decode_stream_sharded_device(codec, sb, rank, world, "cpu", gather=True)
+            if rank == 0:
+                ok = ok and rng_ == (0, len(data)) and whole.numpy().tobytes() == data
+            w2, r2, _ = shard.decode_stream_sharded_device(codec, sb if rank == 0 else None, rank, world, "cpu", gather=True, scatter=True)
+            if rank == 0:
+                ok = ok and w2.numpy().tobytes() == data
+            else:
+                ok = ok and w2.numpy().tobytes() == data[r2[0]:r2[1]]
+            results.append(bool(ok))
+        # errors are raised on EVERY rank, whichever rank's block is bad: a payload byte of the last block flipped -> ErrCRC
+        # (or ErrCorrupt), a truncated stream -> ErrCorrupt from the walk
+        data = synth.text_like(400000, 11).tobytes()
+        sb = bytearray(O.stream_encode(data, 1, 65536))
+        blocks, _ = __import__("minlz_amd.stream", fromlist=["x"]).walk_chunks(bytes(sb))
+        sb[blocks[-1].payload_off + blocks[-1].payload_len - 1] ^= 0x55
+        for bad in (bytes(sb), bytes(sb[:len(sb) // 2])):
+            try:
+                shard.decode_stream_sharded_device(codec, bad, rank, world, "cpu")
+                results.append(False)
+            except (api.ErrCRC, api.ErrCorrupt):
+                results.append(True)
+        q.put((rank, results))
     finally:
         dist.destroy_process_group()
 
@@ -58,11 +88,12 @@ def test_sharded_stream_two_ranks():
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = q.get(timeout=120)
+    got = dict(q.get(timeout=180) for _ in range(2))
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    assert res and all(res), res
+    assert got[0] and all(got[0]), got[0]
+    assert got[1] and all(got[1]), got[1]
 
 
 def test_ownership_is_round_robin():

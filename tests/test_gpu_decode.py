@@ -335,6 +335,21 @@ def test_general_block_barrier_is_bounded(ctx):
     finally:
         ctx.set_option(9, 1 << 24)
     assert mz.decode_batch([own, ref], ctx) == [d.tobytes(), d.tobytes()]
+    # the Reader's entry point (minLZDecode contract: 0 ok, 1 corrupt, < 0 error): a device failure must come back as
+    # < 0 — the shim's cue to run minLZDecodeGo — and never as 1, which the Reader would report as ErrCorrupt for a
+    # valid stream; a really corrupt body still gives 1
+    from minlz_amd.stream import uvarint
+    _, hl = uvarint(ref, 1)
+    body = ref[1 + hl:]
+    assert mz.decode_block(body, d.size, ctx) == (0, d.tobytes())
+    ctx.set_option(9, 1)
+    try:
+        with pytest.raises(mz.ErrHIP):
+            mz.decode_block(body, d.size, ctx)
+    finally:
+        ctx.set_option(9, 1 << 24)
+    assert mz.decode_block(body, d.size, ctx) == (0, d.tobytes())
+    assert mz.decode_block(body[:len(body) // 2], d.size, ctx)[0] == 1
 
 
 def test_token_stream_longer_than_its_output(ctx):

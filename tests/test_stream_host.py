@@ -164,3 +164,47 @@ def test_reader_skip():
     assert r.ReadAll() == d[bs:]
     with pytest.raises(api.ErrCRC):
         S.Reader(bytes(bad), backend=OracleBackend()).ReadAll()
+
+
+def test_walk_chunks_agrees_with_reader():
+    """walk_chunks (the chunk walk a sharded Reader deals blocks from) sees the same blocks, sizes and framing errors as
+    Reader.WriteTo: valid oracle streams at several block sizes and levels (with index and padding chunks behind the EOF),
+    then every single-byte mutation of the framing bytes of a small stream."""
+    import random
+    for d, bs, lvl in ((synth.text_like(300000, 2).tobytes(), 65536, 1), (synth.random_bytes(70000).tobytes(), 4096, 2),
+                       (b"", 4096, 1), (b"abc", 4096, 1), (synth.json_like(400000).tobytes(), 1 << 20, 3)):
+        s = O.stream_encode(d, lvl, bs, add_index=len(d) > 1000)
+        blocks, total = S.walk_chunks(s)
+        assert total == len(d) and sum(b.n for b in blocks) == len(d)
+        assert [b.u_off for b in blocks] == [i * bs for i in range(len(blocks))]
+        for b in blocks:
+            assert s[b.chunk_off] == b.kind and b.payload_off == b.chunk_off + 8
+            if b.kind == S.CHUNK_MINLZ:
+                assert O.decode(b"\x00" + s[b.payload_off:b.payload_off + b.payload_len]) == d[b.u_off:b.u_off + b.n]
+            else:
+                assert s[b.payload_off:b.payload_off + b.payload_len] == d[b.u_off:b.u_off + b.n]
+            assert b.crc == O.crc(d[b.u_off:b.u_off + b.n])
+    d = synth.text_like(20000, 4).tobytes()
+    s = O.stream_encode(d, 1, 4096)
+    blocks, _ = S.walk_chunks(s)
+    framing = list(range(10)) + [o for b in blocks for o in range(b.chunk_off, b.payload_off + b.hdr_len)] + list(range(len(s) - 8, len(s)))
+    rnd = random.Random(5)
+    for pos in framing:
+        bad = bytearray(s); bad[pos] ^= 1 << rnd.randrange(8)
+        try:
+            S.Reader(bytes(bad), backend=OracleBackend()).ReadAll()
+            want = None
+        except api.MinLZError as e:
+            want = type(e)
+        try:
+            S.walk_chunks(bytes(bad))
+            got = None
+        except api.MinLZError as e:
+            got = type(e)
+        # the walk does not decode: CRC and token errors are the workers' to find; everything the framing decides must agree
+        if want in (api.ErrCRC,) or (want is api.ErrCorrupt and got is None):
+            continue
+        assert got == want, (pos, got, want)
+    for cut in (3, 9, 12, len(s) // 2, len(s) - 1):
+        with pytest.raises(api.ErrCorrupt):
+            S.walk_chunks(s[:cut])

@@ -67,7 +67,7 @@ struct Params {
     int lazy_cost;  // 1: lazy compares length minus token size
     int min_far;    // minimum far match (8)
     int probe_stride; // 1: every position is probed; 2: only even positions are (all positions are still inserted); experiment
-    int far_stride2;  // experiment: far probes only at even positions
+    int far_stride2;  // far probes only at positions that are multiples of this (0 / 1: every position); coprime with far_stride so that every (p - q) is found within far_stride * far_stride2 bytes
     int lazy_local;   // 1: the look-ahead does not cross a 64-position window
     int far_hash24;   // 1: far hash from 24-bit multiply-adds
     int far_prev;     // 1: the previous epoch's table is probed as well (LevelBalanced)
@@ -83,7 +83,8 @@ struct Rec { uint32_t mp, len, off; };
 extern "C" {
 
 // Encodes one block; writes the token stream (no block header) to out (cap >= n + n/8 + 64); returns its size.
-// stats[0] = tokens, [1] = literal bytes, [2] = far tokens, [3] = repeat tokens, [4] = windows probed
+// stats[0] = tokens, [1] = literal bytes, [2] = far tokens, [3] = repeat tokens, [4] = positions probed,
+// [8] = near candidates passing the tag bit, [9] = near matches >= 4, [10] = near matches of 8 (extended), [11] = far tag hits, [12] = far candidates equal in 8 bytes  (stats: 16 words)
 size_t model2_block(const uint8_t* src, size_t n, const Params* P, uint8_t* out, uint64_t* stats) {
     g_hash24 = P->far_hash24;
     const uint32_t pat = P->pattern ? P->pattern : P->dense ? kPatternDense : kPatternFast;
@@ -164,6 +165,7 @@ size_t model2_block(const uint8_t* src, size_t n, const Params* P, uint8_t* out,
                         const bool near_ok = cand < p && (e[l] & 0x8000u) == tg[l];
                         const bool rep_ok = P->use_rep && rep != 0 && rep <= p;
                         const uint32_t l_near = near_ok ? common8(v, ld64z(s, cand, tl)) : 0;
+                        if (stats) { stats[8] += near_ok; stats[9] += l_near >= 4; stats[10] += l_near == 8; }
                         const uint32_t l_rep = rep_ok ? common8(v, ld64z(s, p - rep, tl)) : 0;
                         const bool brep = l_rep >= 4;
                         uint32_t b = brep ? l_rep : 0, bo = brep ? rep : 0;
@@ -174,19 +176,21 @@ size_t model2_block(const uint8_t* src, size_t n, const Params* P, uint8_t* out,
                             b = k;
                         }
                         if (b > maxl) b = maxl;
-                        if (use_far && !(P->far_gate && b >= 8) && !(P->far_stride2 && (p & 1))) {
+                        if (use_far && !(P->far_gate && b >= 8) && !(P->far_stride2 > 1 && (p % uint32_t(P->far_stride2)))) {
                             const FarHash fh = far_hash(v, kFarBits);
                             const size_t ep0 = (base + p) >> kEpochLog;
                             for (int kk = 0; kk <= (P->far_prev && ep0 > 0 ? 1 : 0); kk++) {
                             const size_t ep = ep0 - size_t(kk);
                             const uint32_t en = ftab[(ep << kFarBits) + fh.idx];
                             if ((en & kFarTagMask) == fh.tag) {
+                                if (stats) stats[11]++;
                                 const uint32_t fq = en >> kFarTagBits;
                                 const uint32_t off = uint32_t(base) + p - fq;
                                 const uint32_t left = kTile - (fq & (kTile - 1));
                                 if (fq < base && off <= kMaxCopy3Offset && left >= 8) {
                                     uint64_t fv; memcpy(&fv, src + fq, 8);
                                     const bool deep = base + p + 40 <= n;  // the kernel looks at a far candidate only when 32 bytes are readable on both sides
+                                    if (stats && fv == v) stats[12]++;
                                     if (fv == v && maxl >= 8 && deep) {
                                         const uint32_t lm = left < lim ? left : lim;
                                         uint32_t k = 8;

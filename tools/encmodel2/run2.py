@@ -36,7 +36,7 @@ def def_for(nbytes, level=1):
 def run(data, check=True, block=8 << 20, **kw):
     d = dict(DEF); d.update(kw); p = P(**d)
     a = np.ascontiguousarray(data)
-    tot = 0; st = np.zeros(8, dtype=np.uint64)
+    tot = 0; st = np.zeros(16, dtype=np.uint64)
     for o in range(0, a.size, block):
         blk = a[o:o + block]
         out = np.zeros(blk.size + blk.size // 8 + 64, dtype=np.uint8)

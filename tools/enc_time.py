@@ -11,7 +11,7 @@ wl = sys.argv[1] if len(sys.argv) > 1 else "enwik"
 S = 100_000_000; BLOCK = 8 << 20
 host = {"enwik": synth.enwik_like, "text": synth.text_like}[wl](S, 1)
 dev = torch.device("cuda", 0)
-ctx = mz.Context(0)
+ctx = mz.Context(0); ctx.set_option(mz.OPT_ENCODE_FAR, int(os.environ.get("FAR", "1")))
 nb = (S + BLOCK - 1) // BLOCK; stride = BLOCK + 256
 src = torch.from_numpy(host).to(dev); enc = torch.empty(nb * stride, dtype=torch.uint8, device=dev); el = torch.zeros(nb, dtype=torch.int64, device=dev)
 desc = (BlockDesc * nb)(*[BlockDesc(i * BLOCK, min(BLOCK, S - i * BLOCK), i * stride, stride) for i in range(nb)])

@@ -11,6 +11,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#include <stdlib.h>
 
 #include <vector>
 
@@ -105,6 +106,14 @@ size_t model2_block(const uint8_t* src, size_t n, const Params* P, uint8_t* out,
             }
         }
     }
+    // design experiments (not part of the kernels): MODEL_WAYS=2 two entries per near bucket (half the buckets), MODEL_LONG=b a second
+    // near table of 2^b entries indexed by a hash of 8 bytes (MODEL_LONGBYTES: 5..8), candidates of all of them compared, longest taken
+    const int x_heads = getenv("MODEL_FARHEADS") ? atoi(getenv("MODEL_FARHEADS")) : 0;   // a far hit whose offset equals that of the hit 4 lanes before (same 16-lane row) is dropped
+    const int x_ways = getenv("MODEL_WAYS") ? atoi(getenv("MODEL_WAYS")) : 1;
+    const int x_long = getenv("MODEL_LONG") ? atoi(getenv("MODEL_LONG")) : 0;
+    const int x_lbytes = getenv("MODEL_LONGBYTES") ? atoi(getenv("MODEL_LONGBYTES")) : 8;
+    std::vector<uint16_t> table2(size_t(1) << P->near_bits), ltable(x_long ? size_t(1) << x_long : 1);
+    auto lhash = [&](uint64_t v) -> uint32_t { v <<= 8 * (8 - x_lbytes); return uint32_t((v * 0xcf1bbcdcb7a56463ull) >> (64 - x_long)); };
     const uint32_t piece_len = kTile / uint32_t(P->sub);
     const int W = 64, NW = P->nw;
     std::vector<uint16_t> table(size_t(1) << P->near_bits);
@@ -121,12 +130,15 @@ size_t model2_block(const uint8_t* src, size_t n, const Params* P, uint8_t* out,
             const uint32_t pe = ps + piece_len < tl ? ps + piece_len : tl;
             recs.clear();
             std::fill(table.begin(), table.end(), uint16_t(0));
+            std::fill(table2.begin(), table2.end(), uint16_t(0)); std::fill(ltable.begin(), ltable.end(), uint16_t(0));
             const uint32_t tsize = P->graded ? uint32_t(((ps / piece_len) + 1) * (table.size() / size_t(P->sub))) : uint32_t(table.size());
             auto tix = [&](uint32_t h) -> uint32_t { return uint32_t((uint64_t(h) * tsize) >> P->near_bits); };
             if (P->seed)
                 for (uint32_t p = 0; p < ps; p += uint32_t(P->seed_stride)) {   // (mlz_encode2.hip.inc: kSeedStride)
                     const uint32_t h1 = hash4(ld64z(s, p, tl), P->near_bits + 1);
-                    table[tix(h1 >> 1)] = uint16_t(p | ((h1 & 1) << 15));
+                    if (x_ways == 2) table2[tix(h1 >> 1) >> 1] = table[tix(h1 >> 1) >> 1];
+                    table[x_ways == 2 ? tix(h1 >> 1) >> 1 : tix(h1 >> 1)] = uint16_t(p | ((h1 & 1) << 15));
+                    if (x_long) ltable[lhash(ld64z(s, p, tl))] = uint16_t(p);
                 }
             uint32_t cur = ps, pos = ps, rep = 0;
             // the kernel's far pipeline: candidates exist for an iteration only if its windows were the expected ones
@@ -142,19 +154,26 @@ size_t model2_block(const uint8_t* src, size_t n, const Params* P, uint8_t* out,
                 bool valid[256];
                 const int NP = W * NW;
                 for (int w = 0; w < NW; w++) {
-                    uint32_t e[64], hh[64], tg[64];
+                    uint32_t e[64], hh[64], tg[64], e2[64], el[64], hl[64];
                     for (int l = 0; l < W; l++) {
                         const uint32_t p = cur + w * W + l;
                         valid[w * W + l] = p + 4 <= pe;
                         const uint32_t h1 = hash4(ld64z(s, p, tl), P->near_bits + 1);
-                        hh[l] = tix(h1 >> 1); tg[l] = (h1 & 1) << 15;
+                        hh[l] = x_ways == 2 ? tix(h1 >> 1) >> 1 : tix(h1 >> 1); tg[l] = (h1 & 1) << 15;
                         e[l] = table[hh[l]];
+                        e2[l] = x_ways == 2 ? table2[hh[l]] : 0;
+                        hl[l] = x_long ? lhash(ld64z(s, p, tl)) : 0; el[l] = x_long ? ltable[hl[l]] : 0;
                     }
-                    for (int l = 0; l < W; l++) if (valid[w * W + l]) table[hh[l]] = uint16_t((cur + w * W + l) | tg[l]);
+                    for (int l = 0; l < W; l++) if (valid[w * W + l]) {
+                        if (x_ways == 2) table2[hh[l]] = table[hh[l]];
+                        table[hh[l]] = uint16_t((cur + w * W + l) | tg[l]);
+                        if (x_long) ltable[hl[l]] = uint16_t(cur + w * W + l);
+                    }
+                    uint32_t hitoff[64];
                     for (int l = 0; l < W; l++) {
                         const int i = w * W + l;
                         const uint32_t p = cur + i;
-                        best[i] = 0; boff[i] = 0;
+                        best[i] = 0; boff[i] = 0; hitoff[l] = 0;
                         if (!valid[i]) continue;
                         if (P->probe_stride > 1 && (p & uint32_t(P->probe_stride - 1))) continue;
                         if (stats) stats[4]++;
@@ -175,6 +194,15 @@ size_t model2_block(const uint8_t* src, size_t n, const Params* P, uint8_t* out,
                             while (k < lim && s[p + k] == s[p - bo + k]) k++;   // p + k < pe <= tl
                             b = k;
                         }
+                        for (int xc = 0; xc < 2; xc++) {   // experiments: further near candidates, the longest wins
+                            uint32_t c2 = 0xffffffffu;
+                            if (xc == 0 && x_ways == 2 && (e2[l] & 0x8000u) == tg[l]) c2 = e2[l] & 0x7fffu;
+                            if (xc == 1 && x_long) c2 = el[l];
+                            if (c2 >= p) continue;
+                            uint32_t k = 0;
+                            while (k < lim && s[p + k] == s[c2 + k]) k++;
+                            if (k >= 4 && k > b) { b = k; bo = p - c2; }
+                        }
                         if (b > maxl) b = maxl;
                         if (use_far && !(P->far_gate && b >= 8) && !(P->far_stride2 > 1 && (p % uint32_t(P->far_stride2)))) {
                             const FarHash fh = far_hash(v, kFarBits);
@@ -187,6 +215,8 @@ size_t model2_block(const uint8_t* src, size_t n, const Params* P, uint8_t* out,
                                 const uint32_t fq = en >> kFarTagBits;
                                 const uint32_t off = uint32_t(base) + p - fq;
                                 const uint32_t left = kTile - (fq & (kTile - 1));
+                                if (kk == 0 && fq < base) hitoff[l] = off;
+                                if (x_heads && kk == 0 && fq < base && (l & 15) >= x_heads && hitoff[l - x_heads] == off) continue;
                                 if (fq < base && off <= kMaxCopy3Offset && left >= 8) {
                                     uint64_t fv; memcpy(&fv, src + fq, 8);
                                     const bool deep = base + p + 40 <= n;  // the kernel looks at a far candidate only when 32 bytes are readable on both sides

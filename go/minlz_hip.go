@@ -29,6 +29,7 @@ import (
 	"fmt"
 	"io"
 	"sync"
+	"sync/atomic"
 	"unsafe"
 )
 
@@ -140,11 +141,20 @@ func minLZDecode(dst, src []byte) int {
 		return minLZDecodeGo(dst, src)
 	}
 	r := C.mlz_decode_block(c, bytePtr(src), C.size_t(len(src)), bytePtr(dst), C.size_t(len(dst)))
-	if r < 0 { // runtime failure: CPU path
+	if r < 0 { // runtime failure (never a verdict on the input: those are 0 / 1): CPU path, and counted
+		atomic.AddUint64(&hipFallbacks, 1)
 		return minLZDecodeGo(dst, src)
 	}
 	return int(r)
 }
+
+// hipFallbacks counts the block calls that reached the device and came back with a device failure, so that the caller
+// decoded (or encoded) on the CPU instead.  A healthy device leaves it at 0: a monitoring hook for a failing GPU that the
+// silent fallback would otherwise hide.
+var hipFallbacks uint64
+
+// HIPFallbacks returns the number of device failures that were served by the CPU path since the process started.
+func HIPFallbacks() uint64 { return atomic.LoadUint64(&hipFallbacks) }
 
 // HIPEncode is Encode (encode.go:74-139) with the whole block — header included — built on the device.
 func HIPEncode(dst, src []byte, level int) ([]byte, error) {
@@ -163,6 +173,9 @@ func HIPEncode(dst, src []byte, level int) ([]byte, error) {
 	r := C.mlz_encode(c, C.int(level), bytePtr(src), C.size_t(len(src)), bytePtr(dst), C.size_t(len(dst)))
 	if r < 0 {
 		if int(-r) == C.MLZ_ERR_HIP || int(-r) == C.MLZ_ERR_INVALID_LEVEL {
+			if int(-r) == C.MLZ_ERR_HIP {
+				atomic.AddUint64(&hipFallbacks, 1)
+			}
 			return Encode(dst, src, level) // device failure, or LevelSmallest: CPU encoder
 		}
 		return nil, hipError(int(-r))

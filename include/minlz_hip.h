@@ -83,7 +83,11 @@ int64_t mlz_encode_block(mlz_ctx* ctx, int level, const uint8_t* src, size_t n, 
 int mlz_decode_block(mlz_ctx* ctx, const uint8_t* src, size_t c, uint8_t* dst, size_t n);
 /* Batched host-pointer forms used by the wrapper's Writer/Reader (writer.go:501-560,
  * reader.go:830-859 fan blocks to goroutines; here one launch covers the batch).
- * out_len[i] receives the bytes produced for block i or -MLZ_ERR_*. */
+ * out_len[i] receives the bytes produced for block i or -MLZ_ERR_*.
+ * Pinned destinations: when every dst[i] .. dst[i] + dst_cap[i] lies in page-locked host memory (hipHostMalloc /
+ * hipHostRegister), the kernels store their results straight into it and there is no copy-out.  A block that FAILS
+ * (out_len[i] < 0) may then have left partial output in its dst[i] — with pageable destinations a failed block's
+ * buffer is not touched.  Nothing outside dst[i][0 .. dst_cap[i]) is ever written either way. */
 int mlz_encode_batch(mlz_ctx* ctx, int level, int n_blocks, const uint8_t* const* src, const size_t* src_len,
                      uint8_t* const* dst, const size_t* dst_cap, int64_t* out_len);
 int mlz_decode_batch(mlz_ctx* ctx, int n_blocks, const uint8_t* const* src, const size_t* src_len,

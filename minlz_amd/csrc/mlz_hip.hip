@@ -566,8 +566,17 @@ int host_batch(mlz_ctx* c, bool encode, int level, int n, const uint8_t* const* 
     std::vector<uint64_t> mirror(size_t(n), 0);
     bool use_mirror = encode || (c->decode_algo == 0 && c->general_algo == 0);
     for (int i = 0; use_mirror && i < n; i++) {
-        hipPointerAttribute_t at;
+        // (both ends of [dst[i], dst[i] + dst_cap[i]) must lie in the SAME pinned allocation: a buffer that merely starts in one is not ours to write through)
+        hipPointerAttribute_t at, at_end;
         if (hipPointerGetAttributes(&at, dst[i]) != hipSuccess || at.type != hipMemoryTypeHost) { (void)hipGetLastError(); use_mirror = false; break; }
+        if (dst_cap[i] > 1) {
+            const uint8_t* last = dst[i] + dst_cap[i] - 1;
+            if (hipPointerGetAttributes(&at_end, last) != hipSuccess || at_end.type != hipMemoryTypeHost ||
+                (at.devicePointer && at_end.devicePointer &&
+                 static_cast<const uint8_t*>(at_end.devicePointer) - static_cast<const uint8_t*>(at.devicePointer) != ptrdiff_t(dst_cap[i] - 1))) {
+                (void)hipGetLastError(); use_mirror = false; break;
+            }
+        }
         mirror[size_t(i)] = reinterpret_cast<uint64_t>(at.devicePointer ? at.devicePointer : static_cast<void*>(dst[i]));
     }
     const uint64_t* mir = use_mirror ? mirror.data() : nullptr;

@@ -9,8 +9,10 @@ restatement compresses like text of that kind (ratio ~0.47; synth.enwik_like).  
 (synth.text_like, ratio ~0.33) is measured beside it and reported under config.r01_standin.
 
     python bench.py --gpus 1 --steps 20 --warmup 3
+    python bench.py --gpus N ...                      # without a launcher: starts the N ranks itself (fails when the box has fewer GPUs)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
+    python bench.py --mode stream --workload json --level 2 --bytes B [--gpus N]   # BASELINE config 3: ONE stream written and read by N GPUs
 
 Prints ONE JSON line on rank 0.  value = uncompressed bytes through the encode+decode pair per second, whole job
 (all ranks).  roofline = dominant kernel against HBM peak (algorithmic bytes N + C per launch / HIP-event launch
@@ -20,7 +22,10 @@ thread counts with the best one reported, and the single-thread rate.  On rank 0
 carries: config.decode_foreign_MBps (the same stream encoded by the reference's algorithm — every such stream
 takes the decoder's general path; decode_foreign_2MiB_blocks_MBps: the same in blocks of the reference Writer's
 default size), config.end_to_end_MBps (pinned host memory -> mlz_encode_batch /
-mlz_decode_batch -> pinned host memory, PCIe included; never the headline value).
+mlz_decode_batch -> pinned host memory, PCIe included; never the headline value), and short legs for the other BASELINE
+configs at one-GPU scale: config3_json_L2 (JSON stream, LevelBalanced, ratio against the oracle's L2), config4_incompressible_1GiB
+(every block stored), config5_L3_64KiB_decode (4096 x 64 KiB blocks made by the oracle's LevelSmallest on the CPU), small_stream_blocks
+(4 KiB and 16 KiB blocks), each with its kernel times.
 """
 import argparse
 import ctypes as C

@@ -12,13 +12,14 @@ from tests.util import load_zip
 
 pytestmark = pytest.mark.gpu
 
-# Stated ratio tolerances (DESIGN.md "Ratio"), on text-like and JSON-like 8 MiB blocks:
-#   LevelFastest  : C_gpu(1)  <= RATIO_TOL    * C_oracle(L1)   (measured 1.03 / 1.05)
-#   LevelBalanced : C_gpu(2)  <= RATIO_TOL_L2 * C_oracle(L2)   (measured 1.08 / 1.10), and C_gpu(2) <= C_gpu(1)
+# Stated ratio tolerances, on four 8 MiB inputs: the bench stream (enwik-like), the text stand-in, the config-3 JSON
+# stream, the free-text JSON stand-in:
+#   LevelFastest  : C_gpu(1)  <= RATIO_TOL    * C_oracle(L1)   (measured 0.992 / 0.998 / 1.023 / 1.057)
+#   LevelBalanced : C_gpu(2)  <= RATIO_TOL_L2 * C_oracle(L2)   (measured 1.080 / 1.092 / 1.095 / 1.10), and C_gpu(2) <= C_gpu(1)
 #   LevelSuperFast: C_gpu(-1) <= RATIO_TOL_L0 * C_oracle(L0)   (measured 0.90 / 0.87 on text, 1.08 on the JSON stream: 4-byte matches against the reference's 8)
 # and on 64 KiB blocks (the reference's small-block classes, encode_l1.go:285-524 / encode_l0.go:281-522):
 #   C_gpu(1) <= RATIO_TOL_64K * C_oracle(L1)
-RATIO_TOL = 1.08
+RATIO_TOL = 1.06
 RATIO_TOL_L2 = 1.12
 RATIO_TOL_L0 = 1.10   # (text streams 0.87 - 0.90; the config-3 JSON stream 1.084: no far tables at this level)
 RATIO_TOL_64K = 1.08

@@ -255,6 +255,10 @@ def main():
         torch.cuda.set_device(local)
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
         assert dist.get_world_size() == args.gpus, (dist.get_world_size(), args.gpus)   # the ranks RCCL saw
+        # RCCL prints its version banner to the C library's stdout when the communicator is made; behind a pipe that buffer is
+        # flushed at exit, i.e. AFTER the JSON line.  Make the communicator now and flush, so that the JSON line is the last one.
+        _t = torch.zeros(1, device=torch.device("cuda", local)); dist.all_reduce(_t); torch.cuda.synchronize()
+        C.CDLL(None).fflush(None)
     else:
         dist = None
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback exists for the product path)"
@@ -356,6 +360,8 @@ def main():
                 if collective is not None:
                     collective(self.enc_len)
                 self.run_decode()
+                if collective is not None:
+                    collective.post()
             for _ in range(warmup):
                 step()
             torch.cuda.synchronize(dev)
@@ -403,23 +409,30 @@ def main():
         n_all = nblk * world
         pending = []
 
+        h_len = torch.zeros(nblk, dtype=torch.int64, pin_memory=True)
+        len_ready = torch.cuda.Event()
+
         def collective(enc_len):
             # The Writer's exchange (writer.go:219-272): every rank learns every block's compressed size (an RCCL all_gather of
             # nblk int64) and the compressed blocks travel, in stream order, into rank 0's HBM — isend / irecv of one compact
-            # run per rank over xGMI, posted here and overlapped with this rank's decode (which reads its own copy).
+            # run per rank over xGMI, overlapped with this rank's decode (which reads its own copy).
+            # begin (right after the encode launch): the sizes start their way to pinned host memory; nothing waits yet.
+            h_len.copy_(enc_len, non_blocking=True)
+            len_ready.record(torch.cuda.current_stream(dev))
+
+        def post():
+            # (called after the decode LAUNCH: the host waits for the encode's sizes while the device decodes, then posts the gather)
             while pending:
                 shard.finish_gather(pending.pop())
-            sizes = shard.gather_chunk_sizes(enc_len.cpu().tolist(), n_all, rank, world, dev)
+            len_ready.synchronize()
+            sizes = shard.gather_chunk_sizes(h_len.tolist(), n_all, rank, world, dev)
             mine = sizes[rank * nblk:(rank + 1) * nblk]
-            run = torch.empty(max(sum(mine), 1), dtype=torch.uint8, device=dev)
-            o = 0
-            for i, l in enumerate(mine):
-                run[o:o + l] = main_leg.enc[i * main_leg.stride:i * main_leg.stride + l]
-                o += l
+            run = torch.cat([main_leg.enc[i * main_leg.stride:i * main_leg.stride + l] for i, l in enumerate(mine)])   # one kernel
             out, works, payload = shard.start_gather(run, sizes, n_all, rank, world, 0)
             pending.append(works)
             collective.keep = (run, out)          # alive until the transfers are done
             collective.payload = payload
+        collective.post = post
 
         def drain():                              # the last step's transfers belong to the timed region
             while pending:

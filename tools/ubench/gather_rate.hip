@@ -1,6 +1,6 @@
 // Gather-rate microbenchmark for gfx950: how many lane-addresses per cycle a CU's vector memory path takes, for 1-byte loads, aligned
-// and byte-misaligned 4-byte loads, and 4-byte-aligned 16-byte loads, all hitting L2 (a 1 MiB array per workgroup), addresses random
-// per lane.  build: hipcc --offload-arch=gfx950 -O3 -w -o gather_rate gather_rate.hip
+// and byte-misaligned 4-byte loads, and 4-byte-aligned 16-byte loads; addresses random per lane inside a 1 MiB array per workgroup — 256 MiB in all, 32 MiB per
+// XCD: the lines come from the Infinity Cache / HBM, not from the 4 MiB L2 (the regime of the general decoder's phases J and S).  build: hipcc --offload-arch=gfx950 -O3 -w -o gather_rate gather_rate.hip
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdint>

@@ -37,6 +37,11 @@ struct FarHash { uint32_t idx, tag; };
 static int g_hash24 = 0;
 inline uint32_t mul24(uint32_t a, uint32_t b) { return (a & 0xffffffu) * (b & 0xffffffu); }
 inline FarHash far_hash(uint64_t v, int bits) {
+    if (g_hash24 == 2) {   // two 32-bit multiplies (mul_lo issues at the same 4 cycles as the 24-bit forms on gfx950)
+        const uint32_t lo = uint32_t(v), hi = uint32_t(v >> 32);
+        const uint32_t a = (lo * 0x9E3779B1u + hi) * 0x85EBCA77u;
+        return {a >> (32 - bits), (a >> (32 - bits - kFarTagBits)) & kFarTagMask};
+    }
     if (g_hash24) {
         const uint32_t lo = uint32_t(v), hi = uint32_t(v >> 32);
         uint32_t a = mul24(lo, 0x9E3779u);
@@ -132,12 +137,24 @@ size_t model2_block(const uint8_t* src, size_t n, const Params* P, uint8_t* out,
             std::fill(table.begin(), table.end(), uint16_t(0));
             std::fill(table2.begin(), table2.end(), uint16_t(0)); std::fill(ltable.begin(), ltable.end(), uint16_t(0));
             const uint32_t tsize = P->graded ? uint32_t(((ps / piece_len) + 1) * (table.size() / size_t(P->sub))) : uint32_t(table.size());
+            const bool mulhi = P->far_hash24 == 2;   // round-3 hashes: near bucket = mul_hi(hash32, table size), far hash from two 32-bit multiplies
             auto tix = [&](uint32_t h) -> uint32_t { return uint32_t((uint64_t(h) * tsize) >> P->near_bits); };
+            auto nidx = [&](uint64_t v8, uint32_t& tag) -> uint32_t {
+                if (mulhi) {
+                    const uint32_t h32 = uint32_t(v8) * 2654435761u;
+                    tag = (h32 >> (16 - P->near_bits)) & 0x8000u;
+                    return uint32_t((uint64_t(h32) * tsize) >> 32);
+                }
+                const uint32_t h1 = hash4(v8, P->near_bits + 1);
+                tag = (h1 & 1) << 15;
+                return tix(h1 >> 1);
+            };
             if (P->seed)
                 for (uint32_t p = 0; p < ps; p += uint32_t(P->seed_stride)) {   // (mlz_encode2.hip.inc: kSeedStride)
-                    const uint32_t h1 = hash4(ld64z(s, p, tl), P->near_bits + 1);
-                    if (x_ways == 2) table2[tix(h1 >> 1) >> 1] = table[tix(h1 >> 1) >> 1];
-                    table[x_ways == 2 ? tix(h1 >> 1) >> 1 : tix(h1 >> 1)] = uint16_t(p | ((h1 & 1) << 15));
+                    uint32_t stag;
+                    const uint32_t sidx = nidx(ld64z(s, p, tl), stag);
+                    if (x_ways == 2) table2[sidx >> 1] = table[sidx >> 1];
+                    table[x_ways == 2 ? sidx >> 1 : sidx] = uint16_t(p | stag);
                     if (x_long) ltable[lhash(ld64z(s, p, tl))] = uint16_t(p);
                 }
             uint32_t cur = ps, pos = ps, rep = 0;
@@ -158,8 +175,8 @@ size_t model2_block(const uint8_t* src, size_t n, const Params* P, uint8_t* out,
                     for (int l = 0; l < W; l++) {
                         const uint32_t p = cur + w * W + l;
                         valid[w * W + l] = p + 4 <= pe;
-                        const uint32_t h1 = hash4(ld64z(s, p, tl), P->near_bits + 1);
-                        hh[l] = x_ways == 2 ? tix(h1 >> 1) >> 1 : tix(h1 >> 1); tg[l] = (h1 & 1) << 15;
+                        const uint32_t bidx = nidx(ld64z(s, p, tl), tg[l]);
+                        hh[l] = x_ways == 2 ? bidx >> 1 : bidx;
                         e[l] = table[hh[l]];
                         e2[l] = x_ways == 2 ? table2[hh[l]] : 0;
                         hl[l] = x_long ? lhash(ld64z(s, p, tl)) : 0; el[l] = x_long ? ltable[hl[l]] : 0;

@@ -90,3 +90,16 @@ def test_stream_decoded_len_is_host_only():
     assert L.mlz_stream_decoded_len(a.ctypes.data, a.size // 2) == -1          # ErrCorrupt: truncated
     assert L.mlz_stream_bound(len(d), 1 << 20, 1) >= len(st)
     assert L.mlz_stream_bound(len(d), 1000, 0) < 0
+
+
+def test_bench_refuses_a_world_it_cannot_start():
+    """`python bench.py --gpus N` without a launcher starts the N ranks itself and must fail loudly — not run a smaller world
+    under the same label — when the box has fewer than N GPUs (there is none here)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode != 0
+    assert "--gpus 2" in r.stderr and "GPU" in r.stderr
+    assert "{" not in r.stdout          # no JSON line from a run that did not happen

@@ -270,7 +270,7 @@ int encode_device_locked(mlz_ctx* c, hipStream_t st, int level, const uint8_t* d
         // LevelBalanced: far matching forced on, both epochs probed and a cost-aware lazy parse (DESIGN.md "Levels").
         // LevelSuperFast: tile-local matches only (no far tables are built or probed).
         const bool far = ((c->encode_far && level != MLZ_LEVEL_SUPERFAST) || level == MLZ_LEVEL_BALANCED) && maxlen > kTile;
-        const uint32_t pattern = kPatternDense;   // every encoder level (DESIGN.md "Tile levels"); the decoder also knows round 1's kPatternFast
+        const uint32_t pattern = level_pattern_of(level);   // LevelBalanced: dense (four levels); the faster levels: three (DESIGN.md "Tile levels"); the decoder knows both and round 1's kPatternFast
         bool any_big = false, any_small = false;
         for (int i = 0; i < n; i++) (std::min<uint64_t>(desc[i].src_len, kMaxBlockSize) >= kM2BigBlock ? any_big : any_small) = true;
         if (!c->enc_attrs) {  // per context = per device

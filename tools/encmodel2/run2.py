@@ -12,11 +12,11 @@ class P(C.Structure):
     _fields_ = [(k, C.c_int) for k in FIELDS] + [('pattern', C.c_uint), ('graded', C.c_int), ('far_bits', C.c_int), ('far_stride', C.c_int), ('seed_stride', C.c_int)]
 L.model2_block.restype = C.c_size_t
 L.model2_block.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(P), C.c_void_p, C.c_void_p]
-DEF = dict(sub=4, nw=4, near_bits=12, lazy=3, use_rep=0, far=1, lane_cap=32, back=8, dense=1, skip_shift=10, far_gate=0, seed=1, lazy_cost=1, min_far=8, probe_stride=1, far_stride2=0, lazy_local=1, far_hash24=2, far_prev=0, pattern=0, graded=1, far_bits=17, far_stride=4, seed_stride=2)  # = the kernels' defaults for blocks of 1 MiB and more (smaller blocks: near_bits=13, see def_for)
+DEF = dict(sub=4, nw=4, near_bits=12, lazy=3, use_rep=0, far=1, lane_cap=32, back=8, dense=1, skip_shift=10, far_gate=0, seed=1, lazy_cost=1, min_far=8, probe_stride=1, far_stride2=0, lazy_local=1, far_hash24=2, far_prev=0, pattern=0xA9A9A994, graded=1, far_bits=17, far_stride=4, seed_stride=2)  # = the kernels' defaults for blocks of 1 MiB and more (smaller blocks: near_bits=13, see def_for)
 
 # LevelBalanced: 13-bit near tables seeded with every earlier position, far tables twice as dense and twice as large, the
 # previous epoch's table probed as well
-DEF_L2 = dict(DEF, near_bits=13, far_prev=1, far_bits=18, far_stride=2, seed_stride=1)
+DEF_L2 = dict(DEF, near_bits=13, far_prev=1, far_bits=18, far_stride=2, seed_stride=1, pattern=0)   # pattern 0 = the dense four-level pattern; LevelFastest writes the three-level one
 
 def small_far_bits(nbytes, shift=2):
     """mlz_encode.hip.inc small_far_bits: far-table entries (log2) of a LevelFastest block below 1 MiB."""

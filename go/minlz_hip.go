@@ -97,6 +97,9 @@ func hipEncodeBlock(level int) func(dst, src []byte) int {
 		}
 		n := C.mlz_encode_block(c, C.int(level), bytePtr(src), C.size_t(len(src)), bytePtr(dst), C.size_t(len(dst)))
 		if n < 0 {
+			if int(-n) == C.MLZ_ERR_HIP {
+				atomic.AddUint64(&hipFallbacks, 1)
+			}
 			return -1 // HIP failure or a level the device does not serve: let the built-in encoder run
 		}
 		return int(n)

@@ -13,6 +13,8 @@ restatement compresses like text of that kind (ratio ~0.47; synth.enwik_like).  
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
     python bench.py --mode stream --workload json --level 2 --bytes B [--gpus N]   # BASELINE config 3: ONE stream written and read by N GPUs
+    MINLZ_BENCH_ONE_GPU=1 python bench.py --gpus 2 ...  # TEST mode: N ranks, all on cuda:0, over gloo (host-staged) — runs the N > 1
+                                                        # code path on a 1-GPU box; the line carries config.TEST_MODE and is no measurement
 
 Prints ONE JSON line on rank 0.  value = uncompressed bytes through the encode+decode pair per second, whole job
 (all ranks).  roofline = dominant kernel against HBM peak (algorithmic bytes N + C per launch / HIP-event launch
@@ -187,7 +189,7 @@ def stream_mode(args, ctx, mz, synth, dist, dev, rank, world):
     dk_ms = sum(v for k, v in dkern.items() if k.startswith("dec_") or k == "crc")
     per_rank, dper_rank = [k_ms], [dk_ms]
     if dist is not None:
-        tt = torch.tensor([elapsed, k_ms, d_elapsed, dk_ms], dtype=torch.float64, device=dev)
+        tt = torch.tensor([elapsed, k_ms, d_elapsed, dk_ms], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else dev)
         allt = [torch.zeros_like(tt) for _ in range(world)]
         dist.all_gather(allt, tt)
         elapsed = max(float(t[0]) for t in allt)
@@ -207,7 +209,9 @@ def stream_mode(args, ctx, mz, synth, dist, dev, rank, world):
                                      "reader": {"what": "the same stream from host memory on every rank: chunk walk, H2D of the rank's span, device decode + CRC check, output left sharded",
                                                 "decode_MBps": round(total / 1e6 / (d_elapsed / args.steps), 1), "ms_per_step": round(dms, 4),
                                                 "kernel_ms_per_rank": dper_rank, "outside_kernels_ms": round(dms - max(dper_rank), 4)},
-                                     "ranks_rccl": dist.get_world_size() if dist is not None else 1, "device": ctx.device_name()}}), flush=True)
+                                     "ranks_rccl": dist.get_world_size() if dist is not None else 1, "device": ctx.device_name(),
+                                     **({"TEST_MODE": "MINLZ_BENCH_ONE_GPU: all ranks on one GPU over gloo — exercises the N > 1 code path, not a scaling measurement"}
+                                        if dist is not None and dist.get_backend() == "gloo" else {})}}), flush=True)
     if dist is not None:
         dist.destroy_process_group()
 
@@ -234,7 +238,7 @@ def main():
         # `python bench.py --gpus N` without a launcher: start the N ranks here (one process per GPU, the same command the
         # driver uses) and pass rank 0's JSON line through.  Fails loudly when the box has fewer than N GPUs.
         have = torch.cuda.device_count()
-        if have < args.gpus:
+        if have < args.gpus and not (os.environ.get("MINLZ_BENCH_ONE_GPU") and have >= 1):
             sys.exit("bench.py --gpus %d: only %d GPU(s) visible on this box — not running a smaller world under the same label" % (args.gpus, have))
         import socket
         sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
@@ -246,6 +250,12 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # MINLZ_BENCH_ONE_GPU=1 (a TEST mode, never a measurement: the line says so): all ranks share cuda:0, each with its own HIP
+    # context, and talk through gloo with host-staged transfers (RCCL refuses two ranks on one device) — it runs the N > 1 code
+    # path of this file on a 1-GPU box.
+    one_gpu = bool(os.environ.get("MINLZ_BENCH_ONE_GPU"))
+    if one_gpu:
+        local = 0
     assert world == args.gpus, "bench.py --gpus %d was started with WORLD_SIZE=%d: the line would misreport n_gpus" % (args.gpus, world)
     if world > 1 or os.environ.get("MINLZ_BENCH_FORCE_DIST"):   # (the env switch runs the N > 1 code path with one rank: a smoke test)
         import torch.distributed as dist
@@ -253,11 +263,14 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29511")
         os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         torch.cuda.set_device(local)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+        if one_gpu:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
         assert dist.get_world_size() == args.gpus, (dist.get_world_size(), args.gpus)   # the ranks RCCL saw
         # RCCL prints its version banner to the C library's stdout when the communicator is made; behind a pipe that buffer is
         # flushed at exit, i.e. AFTER the JSON line.  Make the communicator now and flush, so that the JSON line is the last one.
-        _t = torch.zeros(1, device=torch.device("cuda", local)); dist.all_reduce(_t); torch.cuda.synchronize()
+        _t = torch.zeros(1, device="cpu" if one_gpu else torch.device("cuda", local)); dist.all_reduce(_t); torch.cuda.synchronize()
         C.CDLL(None).fflush(None)
     else:
         dist = None
@@ -448,10 +461,11 @@ def main():
         torch.cuda.synchronize(dev)
         gather_info = {"root": 0, "payload_bytes_per_step": int(collective.payload), "transport": "isend/irecv of one compact run per rank into rank 0's HBM, overlapped with decode"}
     if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        cdev = "cpu" if dist.get_backend() == "gloo" else dev
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-        ct = torch.tensor([C_total], dtype=torch.int64, device=dev)
+        ct = torch.tensor([C_total], dtype=torch.int64, device=cdev)
         dist.all_reduce(ct)
         C_all = int(ct.item())
     else:
@@ -653,6 +667,8 @@ def main():
            "hbm_read_frac_north_star": round((S / 1e9 / ((enc_ms + dec_ms) / 1e3)) / HBM_PEAK_GBS, 5) if enc_ms + dec_ms else None,
            "ranks_rccl": dist.get_world_size() if dist is not None else 1,
            "device": ctx.device_name()}
+    if dist is not None and dist.get_backend() == "gloo":
+        cfg["TEST_MODE"] = "MINLZ_BENCH_ONE_GPU: all ranks on one GPU over gloo — exercises the N > 1 code path, not a scaling measurement"
     cfg.update(extras)
     if gather_info:
         cfg["gather"] = gather_info

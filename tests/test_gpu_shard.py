@@ -141,3 +141,28 @@ def test_two_ranks_one_gpu_gloo():
         assert p.exitcode == 0
     assert got[0] and all(got[0]), got[0]
     assert got[1] and all(got[1]), got[1]
+
+
+@pytest.mark.parametrize("mode", ["blocks", "stream"])
+def test_bench_two_ranks_on_one_gpu(mode):
+    """bench.py's N > 1 code path (every rank's legs, the size all_gather, the payload gather into rank 0, the max-over-ranks
+    timing, rank 0's line) run for real with two ranks: MINLZ_BENCH_ONE_GPU puts both on cuda:0 over gloo — a test mode the
+    line is labelled with, since an 8-GPU node is not available to the builder."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["MINLZ_BENCH_ONE_GPU"] = "1"
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu", "--no-extras", "--bytes", "33554432"]
+    if mode == "stream":
+        cmd += ["--mode", "stream", "--workload", "json", "--level", "2"]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["config"]["ranks_rccl"] == 2 and "TEST_MODE" in d["config"]
+    if mode == "stream":
+        assert len(d["config"]["kernel_ms_per_rank"]) == 2 and d["config"]["reader"]["decode_MBps"] > 0
+    else:
+        assert d["config"]["gather"]["payload_bytes_per_step"] > 0

@@ -393,7 +393,11 @@ int decode_parallel(mlz_ctx* c, hipStream_t st, const uint8_t* d_src, uint8_t* d
     const size_t o_rout = o_cr + al(size_t(segs) * kSegThreads * 4);
     const size_t o_rlast = o_rout + al(size_t(segs) * kSegThreads * 4);
     const size_t o_rentry = o_rlast + al(size_t(segs) * kSegThreads * 4);
-    const size_t o_order = o_rentry + al(size_t(segs) * kSegThreads * 2);
+    const size_t o_sntok = o_rentry + al(size_t(segs) * kSegThreads * 4);
+    const size_t o_tpos = o_sntok + al(size_t(segs) * 4);                       // token list: a token has at least one stream byte
+    const size_t o_rd = o_tpos + al(size_t(segs) * kSeg * 4);
+    const size_t o_rr = o_rd + al(size_t(segs) * kSegThreads * 4);              // (per 64 tokens: indexed like the 64-byte chunks)
+    const size_t o_order = o_rr + al(size_t(segs) * kSegThreads * 4);
     const size_t o_done = o_order + al(size_t(tiles) * 4);
     const size_t o_ticket = o_done + al(size_t(tiles) * 4);
     const size_t o_gen = o_ticket + 256;  // GenCtl (zeroed with the flags)
@@ -412,7 +416,11 @@ int decode_parallel(mlz_ctx* c, hipStream_t st, const uint8_t* d_src, uint8_t* d
     uint32_t* chunk_rep = reinterpret_cast<uint32_t*>(ws + o_cr);
     uint32_t* reg_out = reinterpret_cast<uint32_t*>(ws + o_rout);
     uint32_t* reg_last = reinterpret_cast<uint32_t*>(ws + o_rlast);
-    uint16_t* reg_entry = reinterpret_cast<uint16_t*>(ws + o_rentry);
+    uint32_t* reg_entry = reinterpret_cast<uint32_t*>(ws + o_rentry);
+    uint32_t* seg_ntok = reinterpret_cast<uint32_t*>(ws + o_sntok);
+    uint32_t* tok_pos = reinterpret_cast<uint32_t*>(ws + o_tpos);
+    uint32_t* round_d = reinterpret_cast<uint32_t*>(ws + o_rd);
+    uint32_t* round_rep = reinterpret_cast<uint32_t*>(ws + o_rr);
     uint32_t* order = reinterpret_cast<uint32_t*>(ws + o_order);
     uint32_t* tile_done = reinterpret_cast<uint32_t*>(ws + o_done);
     uint32_t* ticket = reinterpret_cast<uint32_t*>(ws + o_ticket);
@@ -450,19 +458,20 @@ int decode_parallel(mlz_ctx* c, hipStream_t st, const uint8_t* d_src, uint8_t* d
     {
         Timer t(c, T_DEC_INDEX, st);
         if (segs)
-            hipLaunchKernelGGL(dec_index_a_kernel, dim3(segs), dim3(kSegThreads), kIndexLds, st, d_src, blocks, seg_block, dec, seg_entry, seg_out, seg_last, rexit_tab, reg_out, reg_last, reg_entry);
-        hipLaunchKernelGGL(dec_index_b_kernel, dim3(n), dim3(64), 0, st, blocks, dec, seg_out, seg_last, seg_entry, n);
+            hipLaunchKernelGGL(dec_index_a_kernel, dim3(segs), dim3(kSegThreads), kIndexLds, st, d_src, blocks, seg_block, dec, seg_entry, seg_out, seg_last, rexit_tab, reg_out, reg_last, reg_entry, seg_ntok);
+        hipLaunchKernelGGL(dec_index_b_kernel, dim3(n), dim3(64), 0, st, blocks, dec, seg_out, seg_last, seg_entry, seg_ntok, n);
         if (segs)
             hipLaunchKernelGGL(dec_index_c_kernel, dim3(segs), dim3(kSegThreads), kIndexCLds, st, d_src, blocks, seg_block, dec, seg_entry, seg_out, seg_last,
-                               tile_start, tok_mask, chunk_d, chunk_rep, reg_out, reg_last, reg_entry, jump ? &gen->n_general : nullptr);
+                               tile_start, tok_mask, chunk_d, chunk_rep, reg_out, reg_last, reg_entry, seg_ntok, tok_pos, round_d, round_rep,
+                               jump ? &gen->n_general : nullptr);
         if (tiles) hipLaunchKernelGGL(dec_schedule_kernel, dim3(1), dim3(1024), 0, st, blocks, tile_block, dec, order, tiles);
     }
     {
         Timer t(c, T_DEC_EXEC, st);
         unsigned long long* prof = c->prof_on ? c->d_prof.as<unsigned long long>() : nullptr;
         if (tiles)
-            hipLaunchKernelGGL(dec_exec2_kernel, dim3(tiles), dim3(kExecThreads), kExecLds, st, d_src, d_dst, blocks, tile_block, dec, tile_start, tok_mask,
-                               chunk_d, chunk_rep, order, tile_done, ticket, tiles, prof);
+            hipLaunchKernelGGL(dec_exec2_kernel, dim3(tiles), dim3(kExecThreads), kExecLds, st, d_src, d_dst, blocks, tile_block, dec, tile_start, tok_pos,
+                               round_d, round_rep, order, tile_done, ticket, tiles, prof);
         if (jump && segs) {  // returns at once unless D3c flagged a general block
             if (!c->gen_attr) {
                 HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(dec_general_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kGenLds));

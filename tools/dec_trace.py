@@ -32,8 +32,8 @@ ntiles = sum((l + (32 << 10) - 1) // (32 << 10) for l in blk_len)
 t = t[:ntiles]
 lvl = (t[:, 3] >> np.uint64(60)).astype(int)
 tt = t.copy(); tt[:, 3] &= np.uint64((1 << 60) - 1)
-hwid = (tt[:, 0] >> np.uint64(40)).astype(np.int64); tt[:, 0] &= np.uint64((1 << 40) - 1)
-nchunks = (tt[:, 1] >> np.uint64(48)).astype(int); tt[:, 1] &= np.uint64((1 << 48) - 1)
+hwid = (tt[:, 0] >> np.uint64(40)).astype(np.int64); tt &= np.uint64((1 << 40) - 1)   # (the clock itself has more than 40 bits after some days of uptime: every column is cut the same way)
+nchunks = (t[:, 1] >> np.uint64(48)).astype(int)
 t0 = tt[:, 0].min()
 us = (tt - t0).astype(np.float64) / 100.0  # 100 MHz -> microseconds
 print("tiles", ntiles, "span %.0f us" % us[:, 3].max())
@@ -47,11 +47,12 @@ for L in range(4):
 
 for L in range(4):
     m = lvl == L
+    if not m.any(): continue
     loop = us[m, 2] - us[m, 1]
     nc = nchunks[m]
     r = np.corrcoef(loop, nc)[0, 1]
     fit = np.polyfit(nc, loop, 1)
-    print("level %d: chunks per tile %d..%d (median %d); corr(loop time, chunks) = %.2f; loop = %.2f us/chunk * chunks + %.0f us; residual std %.1f us" % (
+    print("level %d: rounds per tile %d..%d (median %d); corr(loop time, rounds) = %.2f; loop = %.2f us/round * rounds + %.0f us; residual std %.1f us" % (
         L, nc.min(), nc.max(), np.median(nc), r, fit[0], fit[1], np.std(loop - np.polyval(fit, nc))))
 
 # placement: tiles of level 0 per CU and how their loop time depends on it

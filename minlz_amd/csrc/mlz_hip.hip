@@ -387,10 +387,7 @@ int decode_parallel(mlz_ctx* c, hipStream_t st, const uint8_t* d_src, uint8_t* d
     const size_t o_sout = o_entry + al(size_t(segs) * 4);
     const size_t o_slast = o_sout + al(size_t(segs) * 4);
     const size_t o_tstart = o_slast + al(size_t(segs) * 4);
-    const size_t o_mask = o_tstart + al(size_t(tiles) * sizeof(TileStart));
-    const size_t o_cd = o_mask + al(size_t(segs) * kSegThreads * 8);
-    const size_t o_cr = o_cd + al(size_t(segs) * kSegThreads * 4);
-    const size_t o_rout = o_cr + al(size_t(segs) * kSegThreads * 4);
+    const size_t o_rout = o_tstart + al(size_t(tiles) * sizeof(TileStart));
     const size_t o_rlast = o_rout + al(size_t(segs) * kSegThreads * 4);
     const size_t o_rentry = o_rlast + al(size_t(segs) * kSegThreads * 4);
     const size_t o_sntok = o_rentry + al(size_t(segs) * kSegThreads * 4);
@@ -411,9 +408,6 @@ int decode_parallel(mlz_ctx* c, hipStream_t st, const uint8_t* d_src, uint8_t* d
     uint32_t* seg_out = reinterpret_cast<uint32_t*>(ws + o_sout);
     uint32_t* seg_last = reinterpret_cast<uint32_t*>(ws + o_slast);
     TileStart* tile_start = reinterpret_cast<TileStart*>(ws + o_tstart);
-    uint64_t* tok_mask = reinterpret_cast<uint64_t*>(ws + o_mask);
-    uint32_t* chunk_d = reinterpret_cast<uint32_t*>(ws + o_cd);
-    uint32_t* chunk_rep = reinterpret_cast<uint32_t*>(ws + o_cr);
     uint32_t* reg_out = reinterpret_cast<uint32_t*>(ws + o_rout);
     uint32_t* reg_last = reinterpret_cast<uint32_t*>(ws + o_rlast);
     uint32_t* reg_entry = reinterpret_cast<uint32_t*>(ws + o_rentry);
@@ -462,7 +456,7 @@ int decode_parallel(mlz_ctx* c, hipStream_t st, const uint8_t* d_src, uint8_t* d
         hipLaunchKernelGGL(dec_index_b_kernel, dim3(n), dim3(64), 0, st, blocks, dec, seg_out, seg_last, seg_entry, seg_ntok, n);
         if (segs)
             hipLaunchKernelGGL(dec_index_c_kernel, dim3(segs), dim3(kSegThreads), kIndexCLds, st, d_src, blocks, seg_block, dec, seg_entry, seg_out, seg_last,
-                               tile_start, tok_mask, chunk_d, chunk_rep, reg_out, reg_last, reg_entry, seg_ntok, tok_pos, round_d, round_rep,
+                               tile_start, reg_out, reg_last, reg_entry, seg_ntok, tok_pos, round_d, round_rep,
                                jump ? &gen->n_general : nullptr);
         if (tiles) hipLaunchKernelGGL(dec_schedule_kernel, dim3(1), dim3(1024), 0, st, blocks, tile_block, dec, order, tiles);
     }
@@ -483,8 +477,8 @@ int decode_parallel(mlz_ctx* c, hipStream_t st, const uint8_t* d_src, uint8_t* d
                 c->gen_attr = true;
             }
             if (c->gen_grid == 0) { c->err = "dec_general_kernel: the device cannot hold one workgroup per CU"; return -MLZ_ERR_HIP; }
-            hipLaunchKernelGGL(dec_general_kernel, dim3(c->gen_grid), dim3(kGenThreads), kGenLds, st, d_src, d_dst, blocks, seg_block, tile_block, dec, tok_mask,
-                               chunk_d, chunk_rep, tile_start, c->d_idx.as<uint32_t>(), c->d_idx.as<uint8_t>() + idx_bytes, gen, segs, tiles, uint32_t(n),
+            hipLaunchKernelGGL(dec_general_kernel, dim3(c->gen_grid), dim3(kGenThreads), kGenLds, st, d_src, d_dst, blocks, seg_block, tile_block, dec, tok_pos,
+                               round_d, round_rep, tile_start, c->d_idx.as<uint32_t>(), c->d_idx.as<uint8_t>() + idx_bytes, gen, segs, tiles, uint32_t(n),
                                c->gen_spin_limit);
         }
         hipLaunchKernelGGL(dec_finish_kernel, dim3((n + 63) / 64), dim3(64), 0, st, dec, d_out_len, n, c->debug_status);

@@ -98,7 +98,9 @@ int mlz_decode_batch(mlz_ctx* ctx, int n_blocks, const uint8_t* const* src, cons
  * mlz_encode / mlz_decode would have returned for block i.  `desc` is a host array (copied).
  * A context owns ONE workspace: calls issued on different streams are ordered on the device (each waits for the
  * previous call's last kernel through an event), so they are safe but do not overlap; use one context per stream
- * for concurrency. */
+ * for concurrency.  The workspace grows to the largest batch seen and is kept: decode needs about 6.5 bytes per
+ * compressed input byte (region exits, the token list — sized for one token per stream byte), encode about 3 bytes per
+ * input byte plus 1.5 MiB of far tables per 8 MiB block. */
 int mlz_encode_batch_device(mlz_ctx* ctx, void* stream, int level, const uint8_t* d_src, uint8_t* d_dst,
                             const mlz_block_desc* desc, int n_blocks, int64_t* d_out_len);
 int mlz_decode_batch_device(mlz_ctx* ctx, void* stream, const uint8_t* d_src, uint8_t* d_dst,

@@ -383,7 +383,7 @@ int decode_parallel(mlz_ctx* c, hipStream_t st, const uint8_t* d_src, uint8_t* d
     const size_t o_dec = 0;
     const size_t o_exit = o_dec + al(sizeof(DecBlock) * n);
     const size_t o_rexit = o_exit + al(size_t(segs) * kExitKeep * 4);
-    const size_t o_entry = o_rexit + al(size_t(segs) * kSeg * 2);
+    const size_t o_entry = o_rexit + al(size_t(segs) * kSeg);
     const size_t o_sout = o_entry + al(size_t(segs) * 4);
     const size_t o_slast = o_sout + al(size_t(segs) * 4);
     const size_t o_tstart = o_slast + al(size_t(segs) * 4);
@@ -403,7 +403,7 @@ int decode_parallel(mlz_ctx* c, hipStream_t st, const uint8_t* d_src, uint8_t* d
     uint8_t* ws = c->d_dec.as<uint8_t>();
     DecBlock* dec = reinterpret_cast<DecBlock*>(ws + o_dec);
     uint32_t* exit_tab = reinterpret_cast<uint32_t*>(ws + o_exit);
-    uint16_t* rexit_tab = reinterpret_cast<uint16_t*>(ws + o_rexit);
+    uint8_t* rexit_tab = reinterpret_cast<uint8_t*>(ws + o_rexit);
     uint32_t* seg_entry = reinterpret_cast<uint32_t*>(ws + o_entry);
     uint32_t* seg_out = reinterpret_cast<uint32_t*>(ws + o_sout);
     uint32_t* seg_last = reinterpret_cast<uint32_t*>(ws + o_slast);

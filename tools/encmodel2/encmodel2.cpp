@@ -10,6 +10,7 @@
 // build: g++ -O2 -shared -fPIC -o libencmodel2.so encmodel2.cpp -I../../minlz_amd/csrc
 #include <stdint.h>
 #include <stdlib.h>
+#include <stdio.h>
 #include <string.h>
 #include <stdlib.h>
 
@@ -117,6 +118,10 @@ size_t model2_block(const uint8_t* src, size_t n, const Params* P, uint8_t* out,
     const int x_ways = getenv("MODEL_WAYS") ? atoi(getenv("MODEL_WAYS")) : 1;
     const int x_long = getenv("MODEL_LONG") ? atoi(getenv("MODEL_LONG")) : 0;
     const int x_lbytes = getenv("MODEL_LONGBYTES") ? atoi(getenv("MODEL_LONGBYTES")) : 8;
+    // MODEL_MINOFF="a,b,c": tiles of level 0 / 1 / 2 take no near match closer than a / b / c bytes (the decoder's ordered copies of a round of 64
+    // tokens then depend on each other less often: fewer passes on the latency-bound low levels)
+    uint32_t x_minoff[4] = {0, 0, 0, 0};
+    if (getenv("MODEL_MINOFF")) sscanf(getenv("MODEL_MINOFF"), "%u,%u,%u", &x_minoff[0], &x_minoff[1], &x_minoff[2]);
     std::vector<uint16_t> table2(size_t(1) << P->near_bits), ltable(x_long ? size_t(1) << x_long : 1);
     auto lhash = [&](uint64_t v) -> uint32_t { v <<= 8 * (8 - x_lbytes); return uint32_t((v * 0xcf1bbcdcb7a56463ull) >> (64 - x_long)); };
     const uint32_t piece_len = kTile / uint32_t(P->sub);
@@ -198,7 +203,7 @@ size_t model2_block(const uint8_t* src, size_t n, const Params* P, uint8_t* out,
                         const uint32_t maxl = pe - p;
                         const uint32_t lim = maxl < uint32_t(P->lane_cap) ? maxl : uint32_t(P->lane_cap);
                         const uint32_t cand = e[l] & 0x7fffu;
-                        const bool near_ok = cand < p && (e[l] & 0x8000u) == tg[l];
+                        const bool near_ok = cand < p && (e[l] & 0x8000u) == tg[l] && p - cand >= x_minoff[mylv];
                         const bool rep_ok = P->use_rep && rep != 0 && rep <= p;
                         const uint32_t l_near = near_ok ? common8(v, ld64z(s, cand, tl)) : 0;
                         if (stats) { stats[8] += near_ok; stats[9] += l_near >= 4; stats[10] += l_near == 8; }

@@ -119,8 +119,9 @@ def test_long_tokens_spanning_tiles(ctx):
 
 def test_dense_token_streams(ctx):
     # Token streams with far more tokens per stream byte than a compressor writes (1-byte repeats, 2-byte literals, 2-byte
-    # copy1s): the exec pass handles one token per lane in rounds of 64, and groups of four chunks of such streams take three
-    # and more rounds (parts of them while the wave holds the tile's turn).  Output against the oracle's decoder.
+    # copy1s): the exec pass handles one token per lane in rounds of 64 entries of the token list.  With a token per stream
+    # byte a segment has more tokens than the index pass stages in LDS (kTokStage: the rest is written directly) and a tile
+    # has more than 3 x 64 rounds (the waves reload their round records).  Output against the oracle's decoder.
     rng = np.random.default_rng(17)
     for kind in ("rep1", "mixed", "lit1"):
         tok = bytearray(O.emit_literal(b"abcdefgh") + O.emit_copy(3, 5))

@@ -120,6 +120,7 @@ size_t model2_block(const uint8_t* src, size_t n, const Params* P, uint8_t* out,
     const int x_lbytes = getenv("MODEL_LONGBYTES") ? atoi(getenv("MODEL_LONGBYTES")) : 8;
     // MODEL_MINOFF="a,b,c": tiles of level 0 / 1 / 2 take no near match closer than a / b / c bytes (the decoder's ordered copies of a round of 64
     // tokens then depend on each other less often: fewer passes on the latency-bound low levels)
+    const int x_l0pieces = getenv("MODEL_L0PIECES") ? atoi(getenv("MODEL_L0PIECES")) : 0;   // 1: the four 8 KiB pieces of a level-0 tile do not see each other (no seeding, no source before the piece)
     uint32_t x_minoff[4] = {0, 0, 0, 0};
     if (getenv("MODEL_MINOFF")) sscanf(getenv("MODEL_MINOFF"), "%u,%u,%u", &x_minoff[0], &x_minoff[1], &x_minoff[2]);
     std::vector<uint16_t> table2(size_t(1) << P->near_bits), ltable(x_long ? size_t(1) << x_long : 1);
@@ -154,7 +155,7 @@ size_t model2_block(const uint8_t* src, size_t n, const Params* P, uint8_t* out,
                 tag = (h1 & 1) << 15;
                 return tix(h1 >> 1);
             };
-            if (P->seed)
+            if (P->seed && !(x_l0pieces && mylv == 0))
                 for (uint32_t p = 0; p < ps; p += uint32_t(P->seed_stride)) {   // (mlz_encode2.hip.inc: kSeedStride)
                     uint32_t stag;
                     const uint32_t sidx = nidx(ld64z(s, p, tl), stag);
@@ -310,7 +311,7 @@ size_t model2_block(const uint8_t* src, size_t n, const Params* P, uint8_t* out,
                     uint32_t sroom;
                     const uint8_t* a = s + r.mp;
                     const uint8_t* b;
-                    if (r.off <= r.mp) { sroom = r.mp - r.off; b = s + r.mp - r.off; }
+                    if (r.off <= r.mp) { sroom = r.mp - r.off; if (x_l0pieces && mylv == 0) sroom -= ps; b = s + r.mp - r.off; }
                     else { const uint32_t q = uint32_t(base) + r.mp - r.off; sroom = q & (kTile - 1); b = src + q; }
                     if (room > sroom) room = sroom;
                     if (uint32_t(base) + r.mp - r.off < 8) room = 0;  // the kernel compares the 8 bytes before both positions

@@ -21,7 +21,10 @@
 using namespace mlz;
 
 namespace {
-constexpr uint32_t kTileLog = 15, kTile = 1u << kTileLog;
+#ifndef MLZ_TILE_LOG
+#define MLZ_TILE_LOG 15
+#endif
+constexpr uint32_t kTileLog = MLZ_TILE_LOG, kTile = 1u << kTileLog;   // (-DMLZ_TILE_LOG=14: the 16 KiB tile experiment)
 constexpr int kEpochLog = 21, kFarTagBits = 9, kLevels = 4;
 constexpr uint32_t kFarTagMask = (1u << kFarTagBits) - 1;
 constexpr uint32_t kPatternFast = 0xE4E4E4E4u, kPatternDense = 0xEEE7B9E4u;

@@ -209,7 +209,9 @@ def stream_mode(args, ctx, mz, synth, dist, dev, rank, world):
                                      "reader": {"what": "the same stream from host memory on every rank: chunk walk, H2D of the rank's span, device decode + CRC check, output left sharded",
                                                 "decode_MBps": round(total / 1e6 / (d_elapsed / args.steps), 1), "ms_per_step": round(dms, 4),
                                                 "kernel_ms_per_rank": dper_rank, "outside_kernels_ms": round(dms - max(dper_rank), 4)},
-                                     "ranks_rccl": dist.get_world_size() if dist is not None else 1, "device": ctx.device_name(),
+                                     "ranks": dist.get_world_size() if dist is not None else 1,
+                                     "backend": ("rccl (torch nccl)" if dist.get_backend() == "nccl" else dist.get_backend()) if dist is not None else "none (single process)",
+                                     "device": ctx.device_name(),
                                      **({"TEST_MODE": "MINLZ_BENCH_ONE_GPU: all ranks on one GPU over gloo — exercises the N > 1 code path, not a scaling measurement"}
                                         if dist is not None and dist.get_backend() == "gloo" else {})}}), flush=True)
     if dist is not None:
@@ -665,7 +667,8 @@ def main():
            "decode_MBps": round(S / 1e6 / (dec_ms / 1e3), 1) if dec_ms else None,
            "kernel_ms": {k: round(v, 4) for k, v in kavg.items()},
            "hbm_read_frac_north_star": round((S / 1e9 / ((enc_ms + dec_ms) / 1e3)) / HBM_PEAK_GBS, 5) if enc_ms + dec_ms else None,
-           "ranks_rccl": dist.get_world_size() if dist is not None else 1,
+           "ranks": dist.get_world_size() if dist is not None else 1,
+           "backend": ("rccl (torch nccl)" if dist.get_backend() == "nccl" else dist.get_backend()) if dist is not None else "none (single process)",
            "device": ctx.device_name()}
     if dist is not None and dist.get_backend() == "gloo":
         cfg["TEST_MODE"] = "MINLZ_BENCH_ONE_GPU: all ranks on one GPU over gloo — exercises the N > 1 code path, not a scaling measurement"

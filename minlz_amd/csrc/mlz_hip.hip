@@ -790,10 +790,11 @@ int mlz_decode_block(mlz_ctx* c, const uint8_t* src, size_t clen, uint8_t* dst, 
     submit_single(c, rq);
     if (rq.rc) return rq.rc;
     if (rq.out == int64_t(n)) return 0;
-    // Per-block failures that are NOT a verdict on the input (a device failure such as a bounded grid barrier giving up:
-    // -MLZ_ERR_HIP; a block the device declines) are passed on as < 0, so that the caller's shim falls back to its CPU
-    // decoder (go/minlz_hip.go: r < 0) instead of reporting a valid stream as corrupt; everything else is "corrupt" = 1.
-    if (rq.out < 0 && rq.out != -MLZ_ERR_CORRUPT) return int(rq.out);
+    // Only a DEVICE failure (-MLZ_ERR_HIP: a launch that failed, a bounded wait that gave up) is passed on as < 0, the shim's cue
+    // to run its CPU decoder (go/minlz_hip.go: r < 0, counted in hipFallbacks).  Every other per-block code (corrupt, too large,
+    // unsupported, destination too small) is a verdict on the INPUT: minLZDecode's contract has one value for those, 1 = corrupt
+    // (decode.go:26), and a healthy device never makes the caller decode a block twice.
+    if (rq.out == -MLZ_ERR_HIP) return -MLZ_ERR_HIP;
     return 1;
 }
 

@@ -188,8 +188,9 @@ def _host_staged(t):
 
 def gather_chunk_sizes(sizes, n_blocks, rank, world, device):
     """all_gather of the per-block chunk sizes of every rank's range -> list of n_blocks ints in stream order."""
-    if world == 1:
+    if world == 1 and not (dist.is_available() and dist.is_initialized()):
         return list(sizes)
+    # (a one-rank process group still goes through the collective: MINLZ_BENCH_FORCE_DIST runs RCCL's all_gather that way on a 1-GPU box)
     cdev = "cpu" if dist.get_backend() == "gloo" else device
     per = (n_blocks + world - 1) // world
     t = torch.zeros(max(per, 1), dtype=torch.int64, device=cdev)
@@ -317,9 +318,9 @@ def plan_decode(blocks, rank, world):
     return b0, b1, lo, hi, blocks[b0].u_off, blocks[b1 - 1].u_off + blocks[b1 - 1].n
 
 
-def decode_span_device(codec, span, blocks, span_lo, u_lo, device, ignore_crc=False):
-    """Decodes the blocks whose chunks lie in `span` (the stream bytes [span_lo, ...): host bytes / numpy, or a uint8 tensor
-    already on `device` that this call may modify) on `device`.
+def decode_span_device(codec, span, blocks, span_lo, u_lo, device, ignore_crc=False, owned=False):
+    """Decodes the blocks whose chunks lie in `span` (the stream bytes [span_lo, ...): host bytes / numpy, or a uint8 tensor;
+    one already on `device` is copied first unless owned=True says this call may modify it) on `device`.
     -> (decoded uint8 tensor of this range, status: 0 or an MLZ_ERR_* code)."""
     from . import api
     n_out = sum(b.n for b in blocks)
@@ -327,7 +328,9 @@ def decode_span_device(codec, span, blocks, span_lo, u_lo, device, ignore_crc=Fa
     if not blocks:
         return out[:0], 0
     if isinstance(span, torch.Tensor):
-        enc = span if span.device.type == torch.device(device).type else span.to(device)   # (a pinned host tensor uploads at link speed)
+        # (a pinned host tensor uploads at link speed; a tensor already on the target device type is CLONED unless the caller says
+        #  the buffer is this call's to modify — the CRC bytes are zeroed in place below, and a view of the caller's stream would be damaged)
+        enc = span.to(device) if span.device.type != torch.device(device).type else (span if owned else span.clone())
     else:
         enc = torch.from_numpy(np.array(span, dtype=np.uint8, copy=True)).to(device)
     # The decode call wants whole blocks: `00 uvarint(N) tokens` (0x02 / 0x03 chunks: the chunk body behind one zero byte) or
@@ -406,7 +409,15 @@ def decode_stream_sharded_device(codec, stream, rank, world, device, root=0, gat
     else:
         sv = np.frombuffer(stream, dtype=np.uint8) if not isinstance(stream, np.ndarray) else stream
         span = sv[lo:hi]
-    local, status = decode_span_device(codec, span, blocks[b0:b1], lo, u_lo, device, ignore_crc)
+    # A rank whose decode raises (a HIP failure surfaced by the codec) must still reach the all_reduce below, or the others hang:
+    # the exception becomes this rank's status word and is re-raised — as the same error on every rank — behind the exchange.
+    try:
+        local, status = decode_span_device(codec, span, blocks[b0:b1], lo, u_lo, device, ignore_crc,
+                                           owned=scatter and world > 1 and rank != root)
+    except api.MinLZError as e:
+        local, status = torch.empty(0, dtype=torch.uint8, device=device), (e.code or api.ErrHIP.code)
+    except RuntimeError:
+        local, status = torch.empty(0, dtype=torch.uint8, device=device), api.ErrHIP.code
     if world > 1:
         st = torch.tensor([status], dtype=torch.int64, device="cpu" if dist.get_backend() == "gloo" else device)
         dist.all_reduce(st, op=dist.ReduceOp.MAX)

@@ -99,6 +99,8 @@ def test_bench_refuses_a_world_it_cannot_start():
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    # whatever the host has, the subprocess sees no GPU at all: the refusal is what is under test, never a real 2-rank run
+    env["HIP_VISIBLE_DEVICES"] = env["CUDA_VISIBLE_DEVICES"] = env["ROCR_VISIBLE_DEVICES"] = ""
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode != 0
     assert "--gpus 2" in r.stderr and "GPU" in r.stderr

@@ -96,15 +96,21 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, backend="gloo"):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    di = rank if backend == "nccl" else 0          # RCCL: one device per rank; gloo: both contexts on cuda:0
+    torch.cuda.set_device(di)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", di))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     res = []
     try:
         import minlz_amd as mz
-        dev = torch.device("cuda", 0)
-        ctx = mz.Context(0)
+        dev = torch.device("cuda", di)
+        ctx = mz.Context(di)
         codec = shard.HipTensorCodec(ctx)
         for data, bs, lvl in _inputs():
             n_blocks = (len(data) + bs - 1) // bs
@@ -143,6 +149,45 @@ def test_two_ranks_one_gpu_gloo():
     assert got[1] and all(got[1]), got[1]
 
 
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs: RCCL refuses two ranks on one device")
+def test_two_ranks_two_gpus_rccl():
+    """The same exchange over RCCL (device all_gather of the sizes, device-tensor batch_isend_irecv of the runs, scatter / gather of
+    the Reader side): runs wherever two GPUs are visible; the builder's boxes have one."""
+    mpc = mp.get_context("spawn")
+    q = mpc.Queue()
+    port = _free_port()
+    procs = [mpc.Process(target=_worker, args=(r, 2, port, q, "nccl")) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=600) for _ in range(2))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert got[0] and all(got[0]), got[0]
+    assert got[1] and all(got[1]), got[1]
+
+
+@pytest.mark.parametrize("mode", ["blocks", "stream"])
+def test_bench_one_rank_over_rccl(mode):
+    """bench.py with a ONE-rank RCCL process group (MINLZ_BENCH_FORCE_DIST): communicator init, the device all_reduce / all_gather /
+    broadcast_object_list / barrier calls of the N > 1 path execute on the real backend, on the one GPU a builder box has."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MINLZ_BENCH_ONE_GPU")}
+    env["MINLZ_BENCH_FORCE_DIST"] = "1"
+    env["MASTER_PORT"] = str(_free_port())
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--no-cpu", "--no-extras", "--bytes", "33554432"]
+    if mode == "stream":
+        cmd += ["--mode", "stream", "--workload", "json", "--level", "2"]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 1 and d["value"] > 0 and d["config"]["ranks"] == 1 and d["config"]["backend"].startswith("rccl") and "TEST_MODE" not in d["config"]
+
+
 @pytest.mark.parametrize("mode", ["blocks", "stream"])
 def test_bench_two_ranks_on_one_gpu(mode):
     """bench.py's N > 1 code path (every rank's legs, the size all_gather, the payload gather into rank 0, the max-over-ranks
@@ -161,7 +206,7 @@ def test_bench_two_ranks_on_one_gpu(mode):
     assert r.returncode == 0, r.stderr[-2000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     d = json.loads(line)
-    assert d["n_gpus"] == 2 and d["value"] > 0 and d["config"]["ranks_rccl"] == 2 and "TEST_MODE" in d["config"]
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["config"]["ranks"] == 2 and d["config"]["backend"] == "gloo" and "TEST_MODE" in d["config"]
     if mode == "stream":
         assert len(d["config"]["kernel_ms_per_rank"]) == 2 and d["config"]["reader"]["decode_MBps"] > 0
     else:

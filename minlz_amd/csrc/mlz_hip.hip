@@ -50,8 +50,8 @@ constexpr size_t kProfBytes = 256 + kProfTiles * 32;
 // Levels served on the device (encode.go:25-43); LevelSmallest (3) stays on the host side of the boundary.
 inline bool valid_level(int level) { return level >= MLZ_LEVEL_SUPERFAST && level <= MLZ_LEVEL_BALANCED; }
 
-enum { T_FAR = 0, T_ENC_TILES, T_ENC_LAYOUT, T_ENC_GATHER, T_DEC_PARSE, T_DEC_CHAIN, T_DEC_INDEX, T_DEC_EXEC, T_DEC_SERIAL, T_CRC, T_ENC_SER, T_COUNT };
-const char* kTimerNames[T_COUNT] = {"enc_far_build", "enc_tiles", "enc_layout", "enc_gather", "dec_parse", "dec_chain", "dec_index", "dec_exec", "dec_serial", "crc", "enc_serialize"};
+enum { T_FAR = 0, T_ENC_TILES, T_ENC_LAYOUT, T_ENC_GATHER, T_DEC_PARSE, T_DEC_CHAIN, T_DEC_INDEX, T_DEC_EXEC, T_DEC_SERIAL, T_CRC, T_ENC_SER, T_DEC_GENERAL, T_COUNT };
+const char* kTimerNames[T_COUNT] = {"enc_far_build", "enc_tiles", "enc_layout", "enc_gather", "dec_parse", "dec_chain", "dec_index", "dec_exec", "dec_serial", "crc", "enc_serialize", "dec_general"};
 
 }  // namespace
 
@@ -108,9 +108,12 @@ struct mlz_ctx {
     DevBuf d_dec, d_idx;
     int general_algo = 0;  // 0 = pointer-jumping pass for general blocks, 1 = tile chain in the exec pass
     size_t host_group_enc = kHostGroupEncodeDefault, host_group_dec = kHostGroupDecodeDefault;  // host-pointer batches: bytes per overlapped group
-    int gen_grid = 0;      // workgroups of the persistent general-block launch (one per CU)
-    uint32_t gen_spin_limit = 1u << 24;  // grid-barrier patience in polls (~0.3 us each): ~5 s
+    int gen_grid = 0;      // workgroups of dec_general_kernel the device holds at once
+    uint32_t gen_spin_limit = 1u << 24;  // role S's patience with a tile's ready flag, in polls (~0.3 us each): ~5 s
     int n_cus = 0;
+    hipStream_t s_gen = nullptr;      // role S of dec_general_kernel runs here, beside role E on the caller's stream
+    hipEvent_t gen_ev[2] = {nullptr, nullptr};
+    int gen_force_packed = 0;  // tests: every tile of a general block takes the byte-packed pool (the fallback path)
     // host-pointer staging
     DevBuf d_in, d_out, d_len, d_crc;
     // stream calls: copy-in / copy-out streams, event pool, pinned result buffer
@@ -395,7 +398,9 @@ int decode_parallel(mlz_ctx* c, hipStream_t st, const uint8_t* d_src, uint8_t* d
     const size_t o_rd = o_tpos + al(size_t(segs) * kSeg * 4);
     const size_t o_rr = o_rd + al(size_t(segs) * kSegThreads * 4);              // (per 64 tokens: indexed like the 64-byte chunks)
     const size_t o_order = o_rr + al(size_t(segs) * kSegThreads * 4);
-    const size_t o_done = o_order + al(size_t(tiles) * 4);
+    const size_t o_glist = o_order + al(size_t(tiles) * 4);                     // general blocks of the batch (D3d)
+    const size_t o_xcnt = o_glist + al(size_t(n) * 4);                          // per-tile records of dec_general_kernel (GenTile)
+    const size_t o_done = o_xcnt + al(size_t(tiles) * sizeof(GenTile));
     const size_t o_ticket = o_done + al(size_t(tiles) * 4);
     const size_t o_gen = o_ticket + 256;  // GenCtl (zeroed with the flags)
     const size_t total = o_gen + al(sizeof(GenCtl));
@@ -420,11 +425,12 @@ int decode_parallel(mlz_ctx* c, hipStream_t st, const uint8_t* d_src, uint8_t* d
     uint32_t* ticket = reinterpret_cast<uint32_t*>(ws + o_ticket);
     GenCtl* gen = reinterpret_cast<GenCtl*>(ws + o_gen);
     c->last_gen = gen;
-    // General blocks (streams of other encoders) go through the pointer-jumping pass when its 4 B per output
-    // byte of workspace is affordable (<= 4 GiB) and the current exec pass is in use.
-    const size_t idx_bytes = (size_t(tiles) << kTileLog) * 4;
-    const bool jump = c->general_algo == 0 && c->decode_algo == 0 && tiles > 0 && idx_bytes <= (size_t(4) << 30);
-    if (jump) HIPCHK(c, c->d_idx.ensure(idx_bytes + size_t(tiles) * 128));  // + phase J's "all literal" flags, 128 per tile
+    // General blocks (streams of other encoders) go through dec_general_kernel when its workspace — 2 B of map and 1 B of pool per
+    // output byte, 8 B per possible token for the external entries — is affordable (<= 64 GiB) and the current exec pass is in use.
+    const size_t map_bytes = (size_t(tiles) << kTileLog) * 3;   // maps, then pools
+    const size_t ext_entries = (size_t(segs) << kSegLog) + size_t(tiles) * kExtPerTile + 64 * size_t(n);
+    const bool jump = c->general_algo == 0 && c->decode_algo == 0 && tiles > 0 && map_bytes + ext_entries * sizeof(ExtEnt) <= (size_t(64) << 30);
+    if (jump) HIPCHK(c, c->d_idx.ensure(map_bytes + ext_entries * sizeof(ExtEnt) + 256));
     const BlockInfo* blocks = c->d_blocks_cur().as<BlockInfo>();
     const uint32_t* tile_block = c->d_tile_block_cur().as<uint32_t>();
     const uint32_t* seg_block = c->d_seg_block_cur().as<uint32_t>();
@@ -458,7 +464,8 @@ int decode_parallel(mlz_ctx* c, hipStream_t st, const uint8_t* d_src, uint8_t* d
             hipLaunchKernelGGL(dec_index_c_kernel, dim3(segs), dim3(kSegThreads), kIndexCLds, st, d_src, blocks, seg_block, dec, seg_entry, seg_out, seg_last,
                                tile_start, reg_out, reg_last, reg_entry, seg_ntok, tok_pos, round_d, round_rep,
                                jump ? &gen->n_general : nullptr);
-        if (tiles) hipLaunchKernelGGL(dec_schedule_kernel, dim3(1), dim3(1024), 0, st, blocks, tile_block, dec, order, tiles);
+        if (tiles) hipLaunchKernelGGL(dec_schedule_kernel, dim3(1), dim3(1024), 0, st, blocks, tile_block, dec, order, tiles, uint32_t(n),
+                                      jump ? reinterpret_cast<uint32_t*>(ws + o_glist) : nullptr, reinterpret_cast<uint32_t*>(gen));
     }
     {
         Timer t(c, T_DEC_EXEC, st);
@@ -466,20 +473,45 @@ int decode_parallel(mlz_ctx* c, hipStream_t st, const uint8_t* d_src, uint8_t* d
         if (tiles)
             hipLaunchKernelGGL(dec_exec2_kernel, dim3(tiles), dim3(kExecThreads), kExecLds, st, d_src, d_dst, blocks, tile_block, dec, tile_start, tok_pos,
                                round_d, round_rep, order, tile_done, ticket, tiles, prof);
-        if (jump && segs) {  // returns at once unless D3c flagged a general block
+    }
+    {
+        Timer tg(c, T_DEC_GENERAL, st);   // (+ the result pass)
+        if (jump && segs) {  // both kernels return at once unless D3c flagged a general block
             if (!c->gen_attr) {
-                HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(dec_general_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kGenLds));
-                // the persistent launch needs every workgroup resident at once: size it from the occupancy query
-                // (1024 threads + 128 KiB of LDS: one per CU, or none on a device that cannot hold it)
+                HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(dec_general_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, kGenLds));
+                HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(dec_general_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, kGenLds));
+                // how many of these workgroups the device holds at once (1024 threads + 132 KiB of LDS: one per CU).  Not a correctness
+                // requirement — role E never waits and role S only waits for role E —: it sizes E's grid so that the settling
+                // workgroups find free CUs beside the explaining ones instead of behind them.
                 int per_cu = 0;
-                HIPCHK(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(dec_general_kernel), kGenThreads, kGenLds));
-                c->gen_grid = per_cu >= 1 ? c->n_cus : 0;
+                HIPCHK(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(dec_general_kernel<0>), kGenThreads, kGenLds));
+                c->gen_grid = per_cu >= 1 ? c->n_cus * per_cu : 0;
+                if (!c->s_gen) HIPCHK(c, hipStreamCreateWithFlags(&c->s_gen, hipStreamNonBlocking));
+                if (!c->gen_ev[0]) { HIPCHK(c, hipEventCreateWithFlags(&c->gen_ev[0], hipEventDisableTiming)); HIPCHK(c, hipEventCreateWithFlags(&c->gen_ev[1], hipEventDisableTiming)); }
                 c->gen_attr = true;
             }
-            if (c->gen_grid == 0) { c->err = "dec_general_kernel: the device cannot hold one workgroup per CU"; return -MLZ_ERR_HIP; }
-            hipLaunchKernelGGL(dec_general_kernel, dim3(c->gen_grid), dim3(kGenThreads), kGenLds, st, d_src, d_dst, blocks, seg_block, tile_block, dec, tok_pos,
-                               round_d, round_rep, tile_start, c->d_idx.as<uint32_t>(), c->d_idx.as<uint8_t>() + idx_bytes, gen, segs, tiles, uint32_t(n),
-                               c->gen_spin_limit);
+            if (c->gen_grid == 0) { c->err = "dec_general_kernel: the device cannot hold a workgroup"; return -MLZ_ERR_HIP; }
+            // role S: one workgroup per general block, at most a quarter of the device (more blocks take turns); role E: the rest
+            const uint32_t nS = std::max<uint32_t>(1u, std::min<uint32_t>(uint32_t(n), uint32_t(c->gen_grid) / 4));
+            const uint32_t nE = std::max<uint32_t>(1u, uint32_t(c->gen_grid) > nS ? uint32_t(c->gen_grid) - nS : 1u);
+            uint16_t* gmap = c->d_idx.as<uint16_t>();
+            uint8_t* gpool = c->d_idx.as<uint8_t>() + (size_t(tiles) << kTileLog) * 2;
+            ExtEnt* gext = reinterpret_cast<ExtEnt*>(c->d_idx.as<uint8_t>() + map_bytes);
+            GenTile* ginfo = reinterpret_cast<GenTile*>(ws + o_xcnt);
+            const uint32_t* glist = reinterpret_cast<const uint32_t*>(ws + o_glist);
+            HIPCHK(c, hipEventRecord(c->gen_ev[0], st));                 // the index passes (and everything before them on the caller's stream)
+            HIPCHK(c, hipStreamWaitEvent(c->s_gen, c->gen_ev[0], 0));
+            hipLaunchKernelGGL(dec_general_kernel<0>, dim3(nE), dim3(kGenThreads), kGenLds, st, d_src, d_dst, blocks, dec, tok_pos, round_d, round_rep, tile_start,
+                               glist, gmap, gpool, gext, ginfo, tile_done, gen, nS, c->gen_spin_limit, uint32_t(c->gen_force_packed));
+#ifdef MLZ_GEN_ONESTREAM
+            hipStream_t sgen = st;
+#else
+            hipStream_t sgen = c->s_gen;
+#endif
+            hipLaunchKernelGGL(dec_general_kernel<1>, dim3(nS), dim3(kGenThreads), kGenLds, sgen, d_src, d_dst, blocks, dec, tok_pos, round_d, round_rep, tile_start,
+                               glist, gmap, gpool, gext, ginfo, tile_done, gen, nS, c->gen_spin_limit, uint32_t(c->gen_force_packed));
+            HIPCHK(c, hipEventRecord(c->gen_ev[1], sgen));
+            HIPCHK(c, hipStreamWaitEvent(st, c->gen_ev[1], 0));          // the caller's stream goes on when both roles are done
         }
         hipLaunchKernelGGL(dec_finish_kernel, dim3((n + 63) / 64), dim3(64), 0, st, dec, d_out_len, n, c->debug_status);
     }
@@ -702,6 +734,8 @@ void mlz_destroy(mlz_ctx* c) {
         b->release();
     if (c->pinned) (void)hipHostFree(c->pinned);
     if (c->pinned2) (void)hipHostFree(c->pinned2);
+    if (c->s_gen) (void)hipStreamDestroy(c->s_gen);
+    for (hipEvent_t e : c->gen_ev) if (e) (void)hipEventDestroy(e);
     if (c->s_in) (void)hipStreamDestroy(c->s_in);
     if (c->s_out) (void)hipStreamDestroy(c->s_out);
     for (hipEvent_t e : c->evpool) (void)hipEventDestroy(e);
@@ -835,6 +869,7 @@ int mlz_set_option(mlz_ctx* c, int opt, int64_t value) {
     case 12: c->timer_mask = uint32_t(value); return 0;  // which timers record events (bit = index of mlz_timer_name)
     case 10: c->host_group_enc = size_t(value > 0 ? value : 1) << 20; return 0;  // tuning: MiB per group of a host-pointer encode batch
     case 11: c->host_group_dec = size_t(value > 0 ? value : 1) << 20; return 0;  // ... of a decode batch
+    case 13: c->gen_force_packed = int(value); return 0;  // tests: general blocks settle through the byte-packed pool (fallback path of dec_general_kernel)
     case 9: c->gen_spin_limit = value > 0 ? uint32_t(value) : 1u; return 0;  // grid-barrier patience of the general-block pass, in polls (tests)
     case 3: c->debug_status = int(value); return 0;  // debug: report failure sites in the error code
     case 4: {  // debug: per-phase cycle counters (16 x u64: 0-7 encode, 8-15 decode)

@@ -115,7 +115,7 @@ struct mlz_ctx {
     hipEvent_t gen_ev[2] = {nullptr, nullptr};
     int gen_force_packed = 0;  // tests: every tile of a general block takes the byte-packed pool (the fallback path)
     // host-pointer staging
-    DevBuf d_in, d_out, d_len, d_crc;
+    DevBuf d_in, d_out, d_len, d_crc, d_crc_tabs, d_crc_tiles;
     // stream calls: copy-in / copy-out streams, event pool, pinned result buffer
     hipStream_t s_in = nullptr, s_out = nullptr;
     std::vector<hipEvent_t> evpool;
@@ -190,7 +190,7 @@ struct WorkspaceOrder {
 
 // Builds BlockInfo / tile map on the host and uploads them when they differ from the last call.
 int upload_blocks(mlz_ctx* c, hipStream_t st, const mlz_block_desc* desc, int n, bool tiles_from_dst, uint32_t* total_tiles, uint32_t* total_segs = nullptr,
-                  const uint64_t* mirror = nullptr) {
+                  const uint64_t* mirror = nullptr, bool any_length = false /* the CRC pass: tiles for spans of any length */) {
     c->dk = tiles_from_dst ? 1 : 0;
     std::vector<BlockInfo>& prev = c->h_blocks_prev_k[c->dk];
     c->h_blocks.resize(n);
@@ -200,7 +200,7 @@ int upload_blocks(mlz_ctx* c, hipStream_t st, const mlz_block_desc* desc, int n,
         b.src_off = desc[i].src_off; b.src_len = desc[i].src_len; b.dst_off = desc[i].dst_off; b.dst_cap = desc[i].dst_cap;
         b.mirror = mirror ? mirror[i] : 0;
         uint64_t span = tiles_from_dst ? desc[i].dst_cap : desc[i].src_len;
-        if (span > kMaxBlockSize) span = tiles_from_dst ? kMaxBlockSize : 0;
+        if (span > kMaxBlockSize && !any_length) span = tiles_from_dst ? kMaxBlockSize : 0;
         b.first_tile = tiles;
         b.n_tiles = uint32_t((span + kTile - 1) >> kTileLog);
         tiles += b.n_tiles;
@@ -541,23 +541,31 @@ int crc_device_locked(mlz_ctx* c, hipStream_t st, const uint8_t* d_base, const m
     HIPCHK(c, hipSetDevice(c->device));
     WorkspaceOrder order(c, st);
     uint32_t tiles = 0;
-    int r = upload_blocks(c, st, desc, n, false, &tiles);
+    int r = upload_blocks(c, st, desc, n, false, &tiles, nullptr, nullptr, true);
     if (r) return r;
     static CrcPow pw;
-    static bool pw_init = false;
-    if (!pw_init) {
+    static CrcTabs tabs;
+    static std::once_flag once;
+    std::call_once(once, [] {
         uint32_t p = 1u << 30;  // x^1
         pw.x2n[0] = p;
         for (int k = 1; k < 32; k++) pw.x2n[k] = p = crc_mulmod(p, p);
-        pw_init = true;
+        for (uint32_t t = 0; t < 256; t++) {
+            tabs.k128[t] = crc_x2n(pw, 128ull * (255 - t), 3);                 // x^(8 * 128 (255 - t))
+            tabs.ktile[t] = crc_x2n(pw, uint64_t(t) << kTileLog, 3);           // x^(8 * 32768 t)
+        }
+    });
+    if (!c->d_crc_tabs.p) {   // per context (= per device): the two tables of constants
+        HIPCHK(c, c->d_crc_tabs.ensure(sizeof(CrcTabs)));
+        HIPCHK(c, hipMemcpy(c->d_crc_tabs.p, &tabs, sizeof(CrcTabs), hipMemcpyHostToDevice));
     }
-    uint64_t maxlen = 0;
-    for (int i = 0; i < n; i++) maxlen = std::max<uint64_t>(maxlen, desc[i].src_len);
+    HIPCHK(c, c->d_crc_tiles.ensure(sizeof(uint32_t) * (size_t(tiles) + 1)));
     Timer t(c, T_CRC, st);
-    HIPCHK(c, hipMemsetAsync(d_out, 0, sizeof(uint32_t) * n, st));
-    const uint32_t groups = uint32_t((maxlen + kCrcGroup - 1) / kCrcGroup);
-    if (groups) hipLaunchKernelGGL(crc_kernel, dim3(groups, n), dim3(256), 0, st, d_base, c->d_blocks_cur().as<BlockInfo>(), pw, d_out);
-    hipLaunchKernelGGL(crc_mask_kernel, dim3((n + 255) / 256), dim3(256), 0, st, d_out, n);
+    if (tiles)
+        hipLaunchKernelGGL(crc_tile_kernel, dim3(tiles), dim3(256), 0, st, d_base, c->d_blocks_cur().as<BlockInfo>(), c->d_tile_block_cur().as<uint32_t>(),
+                           c->d_crc_tabs.as<CrcTabs>(), pw, c->d_crc_tiles.as<uint32_t>());
+    hipLaunchKernelGGL(crc_block_kernel, dim3(n), dim3(64), 0, st, c->d_blocks_cur().as<BlockInfo>(), c->d_crc_tiles.as<uint32_t>(), c->d_crc_tabs.as<CrcTabs>(), pw,
+                       d_out, n);
     HIPCHK(c, hipGetLastError());
     return 0;
 }
@@ -730,7 +738,7 @@ void mlz_destroy(mlz_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
-    for (DevBuf* b : {&c->d_crc, &c->d_prof, &c->d_blocks_k[0], &c->d_blocks_k[1], &c->d_tile_block_k[0], &c->d_tile_block_k[1], &c->d_seg_block_k[0], &c->d_seg_block_k[1], &c->d_scratch, &c->d_tile_size, &c->d_tile_out, &c->d_flags, &c->d_far, &c->d_recs, &c->d_piece_cnt, &c->d_dec, &c->d_idx, &c->d_in, &c->d_out, &c->d_len})
+    for (DevBuf* b : {&c->d_crc, &c->d_crc_tabs, &c->d_crc_tiles, &c->d_prof, &c->d_blocks_k[0], &c->d_blocks_k[1], &c->d_tile_block_k[0], &c->d_tile_block_k[1], &c->d_seg_block_k[0], &c->d_seg_block_k[1], &c->d_scratch, &c->d_tile_size, &c->d_tile_out, &c->d_flags, &c->d_far, &c->d_recs, &c->d_piece_cnt, &c->d_dec, &c->d_idx, &c->d_in, &c->d_out, &c->d_len})
         b->release();
     if (c->pinned) (void)hipHostFree(c->pinned);
     if (c->pinned2) (void)hipHostFree(c->pinned2);

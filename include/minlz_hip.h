@@ -135,6 +135,11 @@ int64_t mlz_stream_decode(mlz_ctx* ctx, uint32_t flags, const uint8_t* src, size
 /* ---- tuning / introspection (not part of the reference surface) ---- */
 #define MLZ_OPT_DECODE_ALGO 1  /* 0 = parallel (default), 1 = serial one-wave-per-block, 3 = parallel with every block on the tile path (cross-checks) */
 #define MLZ_OPT_ENCODE_FAR 2   /* 0 = tile-local matches only, 1 = + far matches (default) */
+#define MLZ_OPT_L2_FREE 14     /* LevelBalanced: 1 (default) = no tile levels — a copy may read any earlier tile of its window: the ratio of the
+                                * reference's encode_l2.go and better (0.93 - 1.05 x its restatement), and the blocks decode, like the reference's own,
+                                * through the general-block path; 0 = the four-level tile pattern of rounds 1-3 (1.08 - 1.09 x, level-scheduled decode) */
+#define MLZ_OPT_GEN_SPIN 9     /* patience of the general-block decode with a tile's ready flag, in polls (~0.3 us each; default 2^24); tests */
+#define MLZ_OPT_GEN_PACKED 13  /* tests: 1 = general blocks settle through the byte-packed pool (the fallback of tiles whose slots do not fit) */
 int mlz_set_option(mlz_ctx* ctx, int opt, int64_t value);
 /* Milliseconds spent in each kernel family, measured with HIP events on the caller's stream.
  * mlz_set_option(ctx, MLZ_TIMER_ENABLE, 1): the last *_batch_device call (mlz_get_timers waits for it);
@@ -146,8 +151,8 @@ const char* mlz_timer_name(int idx);
 /* Counters of the combining queue behind the single-block host calls (mlz_encode, mlz_encode_block, mlz_decode,
  * mlz_decode_block): concurrent callers — one goroutine per block in the reference's Writer/Reader, writer.go:501-560,
  * reader.go:830-859 — are run as one batched launch.  which: 0 = batches run, 1 = requests served.
- * which = 2: blocks of the last decode call that matched neither tile-level pattern of this library's encoder and went
- * through the position-independent (pointer-jumping) path — 0 for streams made by this library. */
+ * which = 2: blocks of the last decode call that matched no tile-level pattern of this library's encoder and went through the
+ * general-block path (mlz_decode_general.hip.inc): the reference's own blocks, and this library's LevelBalanced ones. */
 int64_t mlz_get_counter(mlz_ctx* ctx, int which);
 
 #ifdef __cplusplus

@@ -113,6 +113,7 @@ struct mlz_ctx {
     int n_cus = 0;
     hipStream_t s_gen = nullptr;      // role S of dec_general_kernel runs here, beside role E on the caller's stream
     hipEvent_t gen_ev[2] = {nullptr, nullptr};
+    int l2_free = 1;           // option 14 (default on): LevelBalanced without the tile-level constraint (better ratio; its blocks decode through the general path)
     int gen_force_packed = 0;  // tests: every tile of a general block takes the byte-packed pool (the fallback path)
     // host-pointer staging
     DevBuf d_in, d_out, d_len, d_crc, d_crc_tabs, d_crc_tiles;
@@ -273,7 +274,7 @@ int encode_device_locked(mlz_ctx* c, hipStream_t st, int level, const uint8_t* d
         // LevelBalanced: far matching forced on, both epochs probed and a cost-aware lazy parse (DESIGN.md "Levels").
         // LevelSuperFast: tile-local matches only (no far tables are built or probed).
         const bool far = ((c->encode_far && level != MLZ_LEVEL_SUPERFAST) || level == MLZ_LEVEL_BALANCED) && maxlen > kTile;
-        const uint32_t pattern = level_pattern_of(level);   // LevelBalanced: dense (four levels); the faster levels: three (DESIGN.md "Tile levels"); the decoder knows both and round 1's kPatternFast
+        const uint32_t pattern = (level == MLZ_LEVEL_BALANCED && c->l2_free) ? kPatternFree : level_pattern_of(level);   // LevelBalanced: dense (four levels); the faster levels: three (DESIGN.md "Tile levels"); the decoder knows both and round 1's kPatternFast
         bool any_big = false, any_small = false;
         for (int i = 0; i < n; i++) (std::min<uint64_t>(desc[i].src_len, kMaxBlockSize) >= kM2BigBlock ? any_big : any_small) = true;
         if (!c->enc_attrs) {  // per context = per device
@@ -877,6 +878,7 @@ int mlz_set_option(mlz_ctx* c, int opt, int64_t value) {
     case 12: c->timer_mask = uint32_t(value); return 0;  // which timers record events (bit = index of mlz_timer_name)
     case 10: c->host_group_enc = size_t(value > 0 ? value : 1) << 20; return 0;  // tuning: MiB per group of a host-pointer encode batch
     case 11: c->host_group_dec = size_t(value > 0 ? value : 1) << 20; return 0;  // ... of a decode batch
+    case 14: c->l2_free = int(value); return 0;  // LevelBalanced: 1 = no tile levels (ratio of the reference's L2 and better; blocks decode as general blocks)
     case 13: c->gen_force_packed = int(value); return 0;  // tests: general blocks settle through the byte-packed pool (fallback path of dec_general_kernel)
     case 9: c->gen_spin_limit = value > 0 ? uint32_t(value) : 1u; return 0;  // grid-barrier patience of the general-block pass, in polls (tests)
     case 3: c->debug_status = int(value); return 0;  // debug: report failure sites in the error code

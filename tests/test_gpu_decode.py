@@ -256,10 +256,18 @@ def test_own_streams_take_the_tile_path(ctx):
     # dense pattern at level 2); only blocks of other encoders with cross-tile copies go through the
     # pointer-jumping path.  Guards against a silent 3x decode slow-down if encoder and decoder ever disagree.
     d = synth.text_like(3 << 20, 9)
-    for level in (-1, 1, 2):
-        e = mz.Encode(d, level, ctx)
-        assert mz.Decode(e, ctx) == d.tobytes()
-        assert ctx.general_blocks() == 0, level
+    ctx.set_option(mz.OPT_L2_FREE, 0)     # LevelBalanced with the tile levels of rounds 1-3
+    try:
+        for level in (-1, 1, 2):
+            e = mz.Encode(d, level, ctx)
+            assert mz.Decode(e, ctx) == d.tobytes()
+            assert ctx.general_blocks() == 0, level
+    finally:
+        ctx.set_option(mz.OPT_L2_FREE, 1)
+    # LevelBalanced's default since round 4 has no tile levels (the reference's ratio): its blocks of more than two tiles are general ones
+    e = mz.Encode(d, 2, ctx)
+    assert mz.Decode(e, ctx) == d.tobytes() and O.decode(e) == d.tobytes()
+    assert ctx.general_blocks() == 1
     e = O.encode(d, 1)   # the reference's algorithm: copies from any earlier byte
     assert mz.Decode(e, ctx) == d.tobytes()
     assert ctx.general_blocks() == 1

@@ -16,12 +16,14 @@ pytestmark = pytest.mark.gpu
 # stream, the free-text JSON stand-in:
 #   LevelFastest  : C_gpu(1)  <= RATIO_TOL[kind] * C_oracle(L1)   (measured 1.006 / 1.023 / 1.030 / 1.065 with the three-level tile pattern of round 3;
 #                                                                     0.992 / 0.998 / 1.023 / 1.057 with the four-level one, which LevelBalanced keeps)
-#   LevelBalanced : C_gpu(2)  <= RATIO_TOL_L2 * C_oracle(L2)   (measured 1.080 / 1.092 / 1.095 / 1.10), and C_gpu(2) <= C_gpu(1)
+#   LevelBalanced : C_gpu(2)  <= RATIO_TOL_L2 * C_oracle(L2)   (measured 0.989 / 0.925 / 1.048 since round 4 — no tile levels, MLZ_OPT_L2_FREE —;
+#                                                                     1.080 / 1.092 / 1.095 with the four-level pattern of rounds 1-3, RATIO_TOL_L2_LEVELS), and C_gpu(2) <= C_gpu(1)
 #   LevelSuperFast: C_gpu(-1) <= RATIO_TOL_L0 * C_oracle(L0)   (measured 0.90 / 0.87 on text, 1.08 on the JSON stream: 4-byte matches against the reference's 8)
 # and on 64 KiB blocks (the reference's small-block classes, encode_l1.go:285-524 / encode_l0.go:281-522):
 #   C_gpu(1) <= RATIO_TOL_64K * C_oracle(L1)
 RATIO_TOL = {"enwik": 1.02, "text": 1.04, "json": 1.04, "json_text": 1.08, "twain": 1.08}
-RATIO_TOL_L2 = 1.12
+RATIO_TOL_L2 = 1.06
+RATIO_TOL_L2_LEVELS = 1.12
 RATIO_TOL_L0 = 1.10   # (text streams 0.87 - 0.90; the config-3 JSON stream 1.084: no far tables at this level)
 RATIO_TOL_64K = 1.08
 RATIO_TOL_SMALL = 1.02   # 4 KiB and 16 KiB blocks (measured 0.92 - 0.99)
@@ -126,6 +128,14 @@ def test_ratio_within_tolerance_of_reference_l1(ctx, kind):
     ref2 = O.encode(d, 2)
     assert len(enc2) <= len(enc), (len(enc2), len(enc))
     assert len(enc2) <= RATIO_TOL_L2 * len(ref2), (len(enc2), len(ref2))
+    # ... and with the tile levels of rounds 1-3 (MLZ_OPT_L2_FREE = 0: level-scheduled decode, 8-9 % more output)
+    ctx.set_option(mz.OPT_L2_FREE, 0)
+    try:
+        enc2l = roundtrip(d, ctx, level=2)
+        assert mz.Decode(enc2l, ctx) == d.tobytes() and ctx.general_blocks() == 0
+    finally:
+        ctx.set_option(mz.OPT_L2_FREE, 1)
+    assert len(enc2) <= len(enc2l) <= RATIO_TOL_L2_LEVELS * len(ref2), (len(enc2), len(enc2l), len(ref2))
 
 
 def test_encode_block_contract(ctx):
@@ -278,7 +288,7 @@ def test_concurrent_single_block_calls(ctx):
 def test_config1_tom_sawyer(ctx, twain, twain_mzb):
     # BASELINE config 1: testdata/Mark.Twain-Tom.Sawyer.txt as a single block (minlz_test.go:626-660 holds its
     # LevelSmallest encoding).  Encode leg on the HIP path at every device level, decode leg with every decode pass.
-    for level, tol in ((mz.LevelFastest, RATIO_TOL["twain"]), (mz.LevelBalanced, RATIO_TOL_L2), (mz.LevelSuperFast, RATIO_TOL_L0)):
+    for level, tol in ((mz.LevelFastest, RATIO_TOL["twain"]), (mz.LevelBalanced, RATIO_TOL_L2_LEVELS), (mz.LevelSuperFast, RATIO_TOL_L0)):   # (one tile: tile levels or none is the same thing)
         enc = roundtrip(twain, ctx, level=level)
         ref = O.encode(twain, level)
         assert len(enc) <= tol * len(ref), (level, len(enc), len(ref))
@@ -438,4 +448,4 @@ def test_host_batch_pinned_destinations(ctx):
         assert dh[o:o + l].tobytes() == p.tobytes()
         keep[o:o + p.size] = False
     assert (dh[keep] == 0x5A).all()
-    assert ctx.general_blocks() == 2
+    assert ctx.general_blocks() == 5      # the two reference-algorithm blocks, and this library's three LevelBalanced blocks of more than two tiles (no tile levels: MLZ_OPT_L2_FREE)

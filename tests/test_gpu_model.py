@@ -30,15 +30,27 @@ def _body(enc):
     return bytes(enc[h + 1:])
 
 
-def _model_body(run2, a, level):
-    p = run2.P(**run2.def_for(a.size, level))
+def _model_body(run2, a, level, l2_free=True):
+    p = run2.P(**run2.def_for(a.size, level, l2_free))
     out = np.zeros(a.size + a.size // 8 + 64, dtype=np.uint8)
     n = run2.L.model2_block(a.ctypes.data, a.size, C.byref(p), out.ctypes.data, None)
     return out[:n].tobytes()
 
 
-@pytest.mark.parametrize("level", [1, 2])
+@pytest.mark.parametrize("level", [1, 2, 20])
 def test_device_output_equals_the_model(ctx, model, level):
+    # (level 20 = LevelBalanced WITH the tile levels of rounds 1-3: option 14 = 0)
+    l2_free = level != 20
+    if level == 20:
+        level = 2
+        ctx.set_option(mz.OPT_L2_FREE, 0)
+    try:
+        _check_model(ctx, model, level, l2_free)
+    finally:
+        ctx.set_option(mz.OPT_L2_FREE, 1)
+
+
+def _check_model(ctx, model, level, l2_free):
     rng = np.random.default_rng(9)
     mix = np.concatenate([synth.text_like(200000, 4), rng.integers(0, 256, 100000, dtype=np.uint8), synth.json_like(150000, 5)])
     cases = [synth.text_like(100000, 7), synth.text_like((1 << 20) + 77, 8), mix, synth.json_like(3 << 20, 2),
@@ -47,8 +59,8 @@ def test_device_output_equals_the_model(ctx, model, level):
     for a in cases:
         a = np.ascontiguousarray(a)
         enc = mz.Encode(a, lv, ctx)
-        assert _body(enc) == _model_body(model, a, level), (level, a.size)
+        assert _body(enc) == _model_body(model, a, level, l2_free), (level, a.size)
     # one batch with blocks of every size class (far tables of different sizes side by side)
     encs = mz.encode_batch([np.ascontiguousarray(a) for a in cases], lv, ctx)
     for a, enc in zip(cases, encs):
-        assert _body(enc) == _model_body(model, np.ascontiguousarray(a), level), (level, a.size, "batch")
+        assert _body(enc) == _model_body(model, np.ascontiguousarray(a), level, l2_free), (level, a.size, "batch")

@@ -97,6 +97,8 @@ extern "C" {
 // [8] = near candidates passing the tag bit, [9] = near matches >= 4, [10] = near matches of 8 (extended), [11] = far tag hits, [12] = far candidates equal in 8 bytes  (stats: 16 words)
 size_t model2_block(const uint8_t* src, size_t n, const Params* P, uint8_t* out, uint64_t* stats) {
     g_hash24 = P->far_hash24;
+    // no tile levels (LevelBalanced's default since round 4, kPatternFree of the kernels): pattern 0xffffffff here, or the environment switch
+    const bool x_nolevel = P->pattern == 0xffffffffu || getenv("MODEL_NOLEVEL") != nullptr;
     const uint32_t pat = P->pattern ? P->pattern : P->dense ? kPatternDense : kPatternFast;
     const int kFarBits = P->far_bits;
     const size_t ntiles = (n + kTile - 1) >> kTileLog;
@@ -107,7 +109,7 @@ size_t model2_block(const uint8_t* src, size_t n, const Params* P, uint8_t* out,
         for (size_t q = 0; q + 8 <= n; q += size_t(P->far_stride)) {
             uint64_t v; memcpy(&v, src + q, 8);
             const FarHash fh = far_hash(v, kFarBits);
-            const int lv = tile_level_p(uint32_t(q >> kTileLog), pat);
+            const int lv = x_nolevel ? 0 : tile_level_p(uint32_t(q >> kTileLog), pat);   // MODEL_NOLEVEL: one table of ALL positions (a copy may read any earlier tile: the block becomes a general one for the decoder)
             for (int ls = lv; ls < kLevels - 1; ls++) {
                 uint32_t& e = far_tab[((size_t(ls) * nepoch + (q >> kEpochLog)) << kFarBits) + fh.idx];
                 const uint32_t val = (uint32_t(q) << kFarTagBits) | fh.tag;
@@ -137,7 +139,7 @@ size_t model2_block(const uint8_t* src, size_t n, const Params* P, uint8_t* out,
         const size_t base = t << kTileLog;
         const uint32_t tl = uint32_t(n - base < kTile ? n - base : kTile);
         const uint8_t* s = src + base;
-        const int mylv = tile_level_p(uint32_t(t), pat);
+        const int mylv = x_nolevel ? (t > 0 ? 1 : 0) : tile_level_p(uint32_t(t), pat);
         const bool far_tile = !far_tab.empty() && mylv > 0;
         const uint32_t* ftab = far_tile ? &far_tab[(size_t(mylv - 1) * nepoch) << kFarBits] : nullptr;
         for (uint32_t ps = 0; ps < tl; ps += piece_len) {

@@ -16,7 +16,8 @@ DEF = dict(sub=4, nw=4, near_bits=12, lazy=3, use_rep=0, far=1, lane_cap=32, bac
 
 # LevelBalanced: 13-bit near tables seeded with every earlier position, far tables twice as dense and twice as large, the
 # previous epoch's table probed as well
-DEF_L2 = dict(DEF, near_bits=13, far_prev=1, far_bits=18, far_stride=2, seed_stride=1, pattern=0)   # pattern 0 = the dense four-level pattern; LevelFastest writes the three-level one
+DEF_L2 = dict(DEF, near_bits=13, far_prev=1, far_bits=18, far_stride=2, seed_stride=1, pattern=0xffffffff)   # pattern 0xffffffff = no tile levels (LevelBalanced's default since round 4); 0 = the dense four-level pattern (option 14 = 0)
+DEF_L2_LEVELS = dict(DEF_L2, pattern=0)
 
 def small_far_bits(nbytes, shift=2):
     """mlz_encode.hip.inc small_far_bits: far-table entries (log2) of a LevelFastest block below 1 MiB."""
@@ -25,10 +26,11 @@ def small_far_bits(nbytes, shift=2):
         lg += 1
     return lg - shift
 
-def def_for(nbytes, level=1):
+def def_for(nbytes, level=1, l2_free=True):
     """The kernels' configuration for a block of nbytes (mlz_encode2.hip.inc: kM2BigBlock)."""
     if level == 2:
-        return dict(DEF_L2) if nbytes >= (1 << 20) else dict(DEF_L2, far_bits=small_far_bits(nbytes) + 1)
+        d2 = DEF_L2 if l2_free else DEF_L2_LEVELS
+        return dict(d2) if nbytes >= (1 << 20) else dict(d2, far_bits=small_far_bits(nbytes) + 1)
     if nbytes >= (1 << 20):
         return dict(DEF)
     return dict(DEF, near_bits=13, far_bits=small_far_bits(nbytes))

@@ -27,7 +27,8 @@ default size), config.end_to_end_MBps (pinned host memory -> mlz_encode_batch /
 mlz_decode_batch -> pinned host memory, PCIe included; never the headline value), and short legs for the other BASELINE
 configs at one-GPU scale: config3_json_L2 (JSON stream, LevelBalanced, ratio against the oracle's L2), config4_incompressible_1GiB
 (every block stored), config5_L3_64KiB_decode (4096 x 64 KiB blocks made by the oracle's LevelSmallest on the CPU), small_stream_blocks
-(4 KiB and 16 KiB blocks), each with its kernel times.
+(4 KiB and 16 KiB blocks), each with its kernel times; config3_json_L2_4GiB (config 3 at its stated size on one GPU: block legs, one
+framed stream written and read, workspace held) and crc (the device CRC pass).
 """
 import argparse
 import ctypes as C
@@ -502,9 +503,15 @@ def main():
                 for kn, kv in tj.get("kernels", {}).items():
                     if kn.startswith(kpref):
                         traffic = kv["traffic"]
+        step_traffic = None
+        if traffic is not None:
+            step_traffic = sum(kv["traffic"] for kv in tj.get("kernels", {}).values())
         roofline = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
-                    "algorithmic_bytes_per_launch": alg, "avg_launch_ms": round(kavg[dom], 4)}
+                    "algorithmic_bytes_per_launch": alg, "avg_launch_ms": round(kavg[dom], 4),
+                    "step_traffic": step_traffic, "step_algorithmic_bytes": 2 * alg,
+                    "traffic_source": ("profiles/pmc_traffic.json: a committed rocprofv3 --pmc run of this workload (%s), not measured in this run"
+                                       % tj.get("commit", "commit not recorded")) if traffic is not None else None}
 
     extras = {}
     if world == 1 and not args.no_extras:
@@ -558,6 +565,20 @@ def main():
         torch.cuda.synchronize(dev)
         extras["decode_foreign_2MiB_blocks_MBps"] = round(S / 1e6 / ((time.perf_counter() - t0) / 10), 1)
         del d_fenc
+        # ---- masked CRC32C of the stream's blocks on the device (what the Writer / Reader add per block, minlz.go:133-140) ----
+        cdesc = [BlockDesc(i * BLOCK, main_leg.blk_len[i], 0, 0) for i in range(nblk)]
+        cout = torch.zeros(nblk, dtype=torch.int32, device=dev)
+        for _ in range(3):
+            ctx.crc_batch_device(stream, main_leg.src.data_ptr(), cdesc, cout.data_ptr())
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(20):
+            ctx.crc_batch_device(stream, main_leg.src.data_ptr(), cdesc, cout.data_ptr())
+        torch.cuda.synchronize(dev)
+        tc = (time.perf_counter() - t0) / 20
+        assert (int(cout[0].item()) & 0xffffffff) == O.crc(host[:main_leg.blk_len[0]]), "device CRC differs from the oracle's"
+        extras["crc"] = {"ms": round(tc * 1e3, 4), "MBps": round(S / 1e6 / tc, 1),
+                         "what": "mlz_crc_batch_device over the stream's %d blocks (one pass over N; the Writer / Reader legs of --mode stream include it)" % nblk}
         # ---- end to end through the host-pointer ABI, pinned memory on both sides (PCIe included) ----
         from minlz_amd import _lib
         L = _lib.lib()
@@ -600,11 +621,63 @@ def main():
             leg = Leg(jd, level=2)
             r = leg.summary(5)
             _, cb2 = O.bench_encode(jd, BLOCK, 2, nth, 1)
-            r["workload"] = "synth.json_like, LevelBalanced (BASELINE config 3 on one GPU)"
+            r["workload"] = ("synth.json_like, LevelBalanced (BASELINE config 3 on one GPU, 12 blocks); since round 4 LevelBalanced writes blocks without tile levels "
+                             "(MLZ_OPT_L2_FREE, the reference's ratio) which decode through the general-block path")
             r["oracle_L2_ratio"] = round(cb2 / jd.size, 4)
             r["ratio_vs_oracle_L2"] = round(r["ratio"] / (cb2 / jd.size), 4)
+            r["general_blocks"] = ctx.general_blocks()
+            ctx.set_option(mz.OPT_L2_FREE, 0)        # the leveled form of rounds 1-3, for comparison
+            try:
+                legl = Leg(jd, level=2)
+                rl = legl.summary(3)
+                r["with_tile_levels"] = {"ratio": rl["ratio"], "ratio_vs_oracle_L2": round(rl["ratio"] / (cb2 / jd.size), 4), "value_MBps": rl["value_MBps"],
+                                         "encode_MBps": rl["encode_MBps"], "decode_MBps": rl["decode_MBps"]}
+                del legl
+            finally:
+                ctx.set_option(mz.OPT_L2_FREE, 1)
             extras["config3_json_L2"] = r
-            del leg, jd
+            del leg
+            # config 3 at its stated size on ONE GPU: 4 GiB of the JSON stream (the 100 MB generator output repeated on the device: blocks
+            # are independent, so what a block compresses to does not depend on its neighbours), 512 blocks of 8 MiB, LevelBalanced:
+            # block legs (encode + decode, HBM-resident), then ONE framed stream written (Writer side) and read back from pinned host
+            # memory (Reader side: chunk walk, H2D, decode + CRC check), with the workspace the context held for it.
+            try:
+                G4 = 4 << 30
+                base = torch.from_numpy(jd).to(dev)
+                big = base.repeat((G4 + S - 1) // S)[:G4].contiguous()
+                del base
+                leg4 = Leg(big, level=2)
+                r4 = leg4.summary(2, warmup=1)
+                r4["general_blocks"] = ctx.general_blocks()
+                ws_e, ws_d = ctx.workspace_bytes()
+                r4["workspace_bytes"] = {"encode": ws_e, "decode": ws_d}
+                del leg4
+                from minlz_amd import shard
+                codec = shard.HipTensorCodec(ctx)
+                torch.cuda.synchronize(dev)
+                t0 = time.perf_counter()
+                out = shard.encode_stream_sharded_device(codec, big, G4, BLOCK, 2, 0, 1)
+                torch.cuda.synchronize(dev)
+                tw = time.perf_counter() - t0
+                sbytes = torch.empty(int(out.numel()), dtype=torch.uint8, pin_memory=True)
+                sbytes.copy_(out)
+                del out
+                torch.cuda.synchronize(dev)
+                t0 = time.perf_counter()
+                local, (ulo, uhi), dtotal = shard.decode_stream_sharded_device(codec, sbytes, 0, 1, dev)
+                torch.cuda.synchronize(dev)
+                tr = time.perf_counter() - t0
+                assert dtotal == G4 and (ulo, uhi) == (0, G4) and torch.equal(local, big), "4 GiB stream round trip mismatch"
+                r4["stream"] = {"stream_bytes": int(sbytes.numel()), "writer_MBps": round(G4 / 1e6 / tw, 1), "reader_MBps": round(G4 / 1e6 / tr, 1),
+                                "note": "one call each (no warm-up): Writer = device-resident source -> framed .mz stream in HBM; Reader = stream in pinned host memory -> "
+                                        "chunk walk, H2D, decode + CRC check, output left in HBM"}
+                r4["workload"] = "4 GiB of synth.json_like (the 100 MB stream repeated), 512 x 8 MiB blocks, LevelBalanced, one GPU (BASELINE config 3 at its stated size)"
+                extras["config3_json_L2_4GiB"] = r4
+                del big, local, sbytes
+            except RuntimeError as ex:      # (a box without the memory for it: say so instead of failing the line)
+                extras["config3_json_L2_4GiB"] = {"skipped": str(ex)[:200]}
+            del jd
+            torch.cuda.empty_cache()
             # config 4: 1 GiB of incompressible bytes: every block must take the stored path (00 00 raw)
             g = torch.Generator(device=dev); g.manual_seed(4)
             rnd = torch.randint(0, 256, (1 << 30,), dtype=torch.uint8, device=dev, generator=g)

@@ -152,7 +152,8 @@ const char* mlz_timer_name(int idx);
  * mlz_decode_block): concurrent callers — one goroutine per block in the reference's Writer/Reader, writer.go:501-560,
  * reader.go:830-859 — are run as one batched launch.  which: 0 = batches run, 1 = requests served.
  * which = 2: blocks of the last decode call that matched no tile-level pattern of this library's encoder and went through the
- * general-block path (mlz_decode_general.hip.inc): the reference's own blocks, and this library's LevelBalanced ones. */
+ * general-block path (mlz_decode_general.hip.inc): the reference's own blocks, and this library's LevelBalanced ones.
+ * which = 3 / 4: bytes of device workspace the context holds for encoding / decoding (grow-only: the high-water mark so far). */
 int64_t mlz_get_counter(mlz_ctx* ctx, int which);
 
 #ifdef __cplusplus

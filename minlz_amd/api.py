@@ -98,6 +98,11 @@ class Context:
         L = _lib.lib()
         return int(L.mlz_get_counter(self.handle, 0)), int(L.mlz_get_counter(self.handle, 1))
 
+    def workspace_bytes(self):
+        """(encode side, decode side): device workspace the context holds — grow-only, i.e. the high-water mark of its calls (mlz_get_counter 3, 4)."""
+        L = _lib.lib()
+        return int(L.mlz_get_counter(self.handle, 3)), int(L.mlz_get_counter(self.handle, 4))
+
     def general_blocks(self):
         """Blocks of the last decode call that took the path for streams of other encoders (mlz_get_counter 2)."""
         return int(_lib.lib().mlz_get_counter(self.handle, 2))

@@ -111,8 +111,6 @@ struct mlz_ctx {
     int gen_grid = 0;      // workgroups of dec_general_kernel the device holds at once
     uint32_t gen_spin_limit = 1u << 24;  // role S's patience with a tile's ready flag, in polls (~0.3 us each): ~5 s
     int n_cus = 0;
-    hipStream_t s_gen = nullptr;      // role S of dec_general_kernel runs here, beside role E on the caller's stream
-    hipEvent_t gen_ev[2] = {nullptr, nullptr};
     int l2_free = 1;           // option 14 (default on): LevelBalanced without the tile-level constraint (better ratio; its blocks decode through the general path)
     int gen_force_packed = 0;  // tests: every tile of a general block takes the byte-packed pool (the fallback path)
     // host-pointer staging
@@ -477,42 +475,25 @@ int decode_parallel(mlz_ctx* c, hipStream_t st, const uint8_t* d_src, uint8_t* d
     }
     {
         Timer tg(c, T_DEC_GENERAL, st);   // (+ the result pass)
-        if (jump && segs) {  // both kernels return at once unless D3c flagged a general block
+        if (jump && segs) {  // returns at once unless D3c flagged a general block
             if (!c->gen_attr) {
-                HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(dec_general_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, kGenLds));
-                HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(dec_general_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, kGenLds));
-                // how many of these workgroups the device holds at once (1024 threads + 132 KiB of LDS: one per CU).  Not a correctness
-                // requirement — role E never waits and role S only waits for role E —: it sizes E's grid so that the settling
-                // workgroups find free CUs beside the explaining ones instead of behind them.
+                HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(dec_general_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kGenLds));
+                // how many of its workgroups the device holds at once (1024 threads + 132 KiB of LDS: one per CU).  Not a correctness
+                // requirement — role E never waits and role S only waits for role E, whose workgroups come first in the grid —: it
+                // sizes the grid so that the settling workgroups start beside the explaining ones instead of behind them.
                 int per_cu = 0;
-                HIPCHK(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(dec_general_kernel<0>), kGenThreads, kGenLds));
+                HIPCHK(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(dec_general_kernel), kGenThreads, kGenLds));
                 c->gen_grid = per_cu >= 1 ? c->n_cus * per_cu : 0;
-                if (!c->s_gen) HIPCHK(c, hipStreamCreateWithFlags(&c->s_gen, hipStreamNonBlocking));
-                if (!c->gen_ev[0]) { HIPCHK(c, hipEventCreateWithFlags(&c->gen_ev[0], hipEventDisableTiming)); HIPCHK(c, hipEventCreateWithFlags(&c->gen_ev[1], hipEventDisableTiming)); }
                 c->gen_attr = true;
             }
             if (c->gen_grid == 0) { c->err = "dec_general_kernel: the device cannot hold a workgroup"; return -MLZ_ERR_HIP; }
             // role S: one workgroup per general block, at most a quarter of the device (more blocks take turns); role E: the rest
             const uint32_t nS = std::max<uint32_t>(1u, std::min<uint32_t>(uint32_t(n), uint32_t(c->gen_grid) / 4));
             const uint32_t nE = std::max<uint32_t>(1u, uint32_t(c->gen_grid) > nS ? uint32_t(c->gen_grid) - nS : 1u);
-            uint16_t* gmap = c->d_idx.as<uint16_t>();
-            uint8_t* gpool = c->d_idx.as<uint8_t>() + (size_t(tiles) << kTileLog) * 2;
-            ExtEnt* gext = reinterpret_cast<ExtEnt*>(c->d_idx.as<uint8_t>() + map_bytes);
-            GenTile* ginfo = reinterpret_cast<GenTile*>(ws + o_xcnt);
-            const uint32_t* glist = reinterpret_cast<const uint32_t*>(ws + o_glist);
-            HIPCHK(c, hipEventRecord(c->gen_ev[0], st));                 // the index passes (and everything before them on the caller's stream)
-            HIPCHK(c, hipStreamWaitEvent(c->s_gen, c->gen_ev[0], 0));
-            hipLaunchKernelGGL(dec_general_kernel<0>, dim3(nE), dim3(kGenThreads), kGenLds, st, d_src, d_dst, blocks, dec, tok_pos, round_d, round_rep, tile_start,
-                               glist, gmap, gpool, gext, ginfo, tile_done, gen, nS, c->gen_spin_limit, uint32_t(c->gen_force_packed));
-#ifdef MLZ_GEN_ONESTREAM
-            hipStream_t sgen = st;
-#else
-            hipStream_t sgen = c->s_gen;
-#endif
-            hipLaunchKernelGGL(dec_general_kernel<1>, dim3(nS), dim3(kGenThreads), kGenLds, sgen, d_src, d_dst, blocks, dec, tok_pos, round_d, round_rep, tile_start,
-                               glist, gmap, gpool, gext, ginfo, tile_done, gen, nS, c->gen_spin_limit, uint32_t(c->gen_force_packed));
-            HIPCHK(c, hipEventRecord(c->gen_ev[1], sgen));
-            HIPCHK(c, hipStreamWaitEvent(st, c->gen_ev[1], 0));          // the caller's stream goes on when both roles are done
+            hipLaunchKernelGGL(dec_general_kernel, dim3(nE + nS), dim3(kGenThreads), kGenLds, st, d_src, d_dst, blocks, dec, tok_pos, round_d, round_rep, tile_start,
+                               reinterpret_cast<const uint32_t*>(ws + o_glist), c->d_idx.as<uint16_t>(), c->d_idx.as<uint8_t>() + (size_t(tiles) << kTileLog) * 2,
+                               reinterpret_cast<ExtEnt*>(c->d_idx.as<uint8_t>() + map_bytes), reinterpret_cast<GenTile*>(ws + o_xcnt), tile_done, gen, nE, nS,
+                               c->gen_spin_limit, uint32_t(c->gen_force_packed));
         }
         hipLaunchKernelGGL(dec_finish_kernel, dim3((n + 63) / 64), dim3(64), 0, st, dec, d_out_len, n, c->debug_status);
     }
@@ -743,8 +724,6 @@ void mlz_destroy(mlz_ctx* c) {
         b->release();
     if (c->pinned) (void)hipHostFree(c->pinned);
     if (c->pinned2) (void)hipHostFree(c->pinned2);
-    if (c->s_gen) (void)hipStreamDestroy(c->s_gen);
-    for (hipEvent_t e : c->gen_ev) if (e) (void)hipEventDestroy(e);
     if (c->s_in) (void)hipStreamDestroy(c->s_in);
     if (c->s_out) (void)hipStreamDestroy(c->s_out);
     for (hipEvent_t e : c->evpool) (void)hipEventDestroy(e);
@@ -923,6 +902,13 @@ int64_t mlz_get_counter(mlz_ctx* c, int which) {
         if (hipSetDevice(c->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess ||
             hipMemcpy(&v, c->last_gen, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) return -MLZ_ERR_HIP;
         return int64_t(v);
+    }
+    if (which == 3 || which == 4) {  // device workspace this context holds: 3 = encode side, 4 = decode side (grow-only buffers: the high-water mark of the calls so far)
+        std::lock_guard<std::mutex> lk(c->mu);
+        size_t e = 0, d = 0;
+        for (const DevBuf* b : {&c->d_scratch, &c->d_tile_size, &c->d_tile_out, &c->d_flags, &c->d_far, &c->d_recs, &c->d_piece_cnt}) e += b->cap;
+        for (const DevBuf* b : {&c->d_dec, &c->d_idx}) d += b->cap;
+        return int64_t(which == 3 ? e : d);
     }
     std::lock_guard<std::mutex> lk(c->q_mu);
     return which == 0 ? int64_t(c->q_batches) : which == 1 ? int64_t(c->q_requests) : -MLZ_ERR_ARG;

@@ -213,8 +213,8 @@ def test_decode_batch(ctx):
 
 
 def test_general_block_paths_agree(ctx):
-    # Streams of other encoders ("general" blocks) have two decode paths: byte-granular pointer jumping (default)
-    # and the tile chain (option 8 = 1).  Both must give the oracle's bytes and the oracle's verdicts.
+    # Streams of other encoders ("general" blocks) have two decode paths: dec_general_kernel (default: explain + settle)
+    # and the tile chain of the exec pass (option 8 = 1).  Both must give the oracle's bytes and the oracle's verdicts.
     import numpy as np
     items = [synth.text_like(3 << 20, 77), synth.json_like(1 << 20), synth.pattern("off2", 300000), synth.pattern("zeros", 200000),
              synth.large_offset(3 << 20, 1 << 20)]
@@ -279,9 +279,46 @@ def test_own_streams_take_the_tile_path(ctx):
         assert ctx.general_blocks() == 0, lv
 
 
+def test_general_blocks_through_the_packed_pool(ctx):
+    # The general-block path lays a tile's terminal bytes out in a 32 KiB pool: literals at the bottom, an 8-byte slot per external
+    # entry at the top; a tile whose slots do not fit is redone with a byte-packed pool (exact stores in the settle pass).  Real
+    # streams rarely need that, so the fallback is forced here (MLZ_OPT_GEN_PACKED) on the inputs of the path's other tests —
+    # same bytes as the oracle, same verdicts — and then a stream that needs it for real: one-byte external runs (a repeat of
+    # length 1 per output byte, from 32 KiB back) fill more slots than a pool has.
+    items = [synth.text_like(3 << 20, 77), synth.json_like(1 << 20), synth.large_offset(3 << 20, 1 << 20), synth.enwik_like((8 << 20) - 13, 5)]
+    encs = [O.encode(d, lv) for d in items for lv in (1, 2, 3)]
+    want = [d.tobytes() for d in items for _ in (1, 2, 3)]
+    ctx.set_option(mz.OPT_GEN_PACKED, 1)
+    try:
+        assert mz.decode_batch(encs, ctx) == want
+        assert ctx.general_blocks() == len(encs)
+    finally:
+        ctx.set_option(mz.OPT_GEN_PACKED, 0)
+    assert mz.decode_batch(encs, ctx) == want
+    # hand-made: 128 KiB of literal-free output after a first tile of noise: copy2 tokens of 4 bytes from exactly 32768 back, i.e. every
+    # token of tiles 1 .. 4 is an external run of 4 bytes: 8192 entries per tile (the slots hold 4096).  (Five tiles: tile 4 reads tile 3,
+    # which no level pattern allows — a general block.)
+    rng = np.random.default_rng(4)
+    first = rng.integers(0, 256, 32768, dtype=np.uint8).tobytes()
+    body = bytearray()
+    pos = 0
+    while pos < len(first):          # literal runs of 29 bytes (one-byte headers)
+        n = min(29, len(first) - pos)
+        body += bytes([(n - 1) << 3]) + first[pos:pos + n]
+        pos += n
+    ntok = 4 * 32768 // 4
+    off = 32768 - 64                 # copy2: offset - 64 in two bytes
+    body += bytes([(4 - 4) << 2 | 2, off & 0xff, off >> 8]) * ntok
+    want2 = first * 5
+    code, got = mz.decode_block(bytes(body), len(want2), ctx)
+    assert (code, got) == (0, want2)
+    assert O.decode_body(bytes(body), len(want2)) == (0, want2)
+    assert ctx.general_blocks() == 1
+
+
 def test_many_general_blocks_take_the_tile_ordered_phase(ctx):
-    # 20 or more general blocks in one batch are resolved tile by tile in order (phase S of mlz_decode_general.hip.inc)
-    # instead of by pointer-jumping rounds: same bytes, same verdicts.
+    # Many general blocks in one batch (more than the settling workgroups the launch has: they take turns), blocks of ragged sizes,
+    # one long block among short ones, one corrupt block among good ones: same bytes, same verdicts as the oracle.
     d = synth.text_like(24 * (256 << 10), 13)
     blocks = [d[i * (256 << 10):(i + 1) * (256 << 10)].tobytes() for i in range(24)]
     blocks[5] = synth.json_like(200_001).tobytes()          # ragged size, other statistics
@@ -289,8 +326,7 @@ def test_many_general_blocks_take_the_tile_ordered_phase(ctx):
     encs = [O.encode(b, 1 + (i % 3)) for i, b in enumerate(blocks)]
     assert mz.decode_batch(encs, ctx) == blocks
     assert ctx.general_blocks() >= 20
-    # one long block among many short ones: the choice between the two routes weighs tiles, not blocks (this batch goes through
-    # the jumping rounds: the ordered phase would take as long as the long block has tiles)
+    # one long block among many short ones
     big = synth.text_like(3 << 20, 29).tobytes()
     mixed = [O.encode(big, 1)] + encs[:22]
     assert mz.decode_batch(mixed, ctx) == [big] + blocks[:22]
@@ -318,12 +354,11 @@ def test_many_general_blocks_take_the_tile_ordered_phase(ctx):
 
 
 def test_general_block_barrier_is_bounded(ctx):
-    # The pass for general blocks (streams of the reference's own encoders) is one persistent launch with grid
-    # barriers.  Co-residency of its workgroups is sized from the occupancy query but is not a promise (another process,
-    # a CU mask), so the barrier's wait is bounded.  With the patience cut to a single poll the first barrier cannot
-    # complete (the workgroups leave phase E microseconds apart): the call must come back with ErrHIP — the Go wrapper's
-    # cue to fall back to its CPU path, INTEGRATION.md — instead of hanging, and with the default patience restored the
-    # same call must decode normally.
+    # The pass for general blocks (streams of the reference's own encoders) has settling workgroups that wait for the ready
+    # flags of the explaining ones.  Nothing but speed depends on the two running side by side, but a wait in a kernel is still a
+    # wait: it is bounded.  With the patience cut to a single poll the first flag cannot be up in time (a tile takes ~30 us to
+    # explain): the call must come back with ErrHIP — the Go wrapper's cue to fall back to its CPU path, INTEGRATION.md — instead
+    # of hanging, and with the default patience restored the same call must decode normally.
     d = synth.text_like(3 << 20, 17)
     ref = O.encode(d, 1)                      # reference-algorithm stream: a general block
     assert mz.Decode(ref, ctx) == d.tobytes()

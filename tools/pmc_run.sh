@@ -8,4 +8,4 @@ for set in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_V
   timeout 900 rocprofv3 --kernel-trace --pmc $set -d $R/gpurun_out/pmc_$i -o p$i -- python $R/bench.py --steps 2 --warmup 1 --no-cpu --no-extras $BENCH_ARGS > $R/gpurun_out/pmc_$i.log 2>&1
   echo "pass $i rc=$?"
 done
-python $R/tools/pmc_traffic.py $R/gpurun_out/pmc_2/p2_results.db $R/gpurun_out/pmc_3/p3_results.db $R/gpurun_out/pmc_traffic.json 100000000 enwik
+python $R/tools/pmc_traffic.py $R/gpurun_out/pmc_2/p2_results.db $R/gpurun_out/pmc_3/p3_results.db $R/gpurun_out/pmc_traffic.json 100000000 enwik "$(cat $R/tools/var/commit.txt 2>/dev/null || echo unknown)"

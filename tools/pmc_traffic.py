@@ -5,7 +5,7 @@ section) prescribes: FETCH_SIZE and WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE 
 128 B request of a wide coalesced read, i.e. reads half the true bytes -> doubled.  The doubling was
 checked here on encode_gather_kernel (a pure 16 B/lane copy of C bytes: FETCH_SIZE*2 = C within 2 %,
 WRITE_SIZE = C); for the gather-dominated kernels (far-table probes) it is an upper bound.
-Usage: tools/pmc_traffic.py fetch.db write.db out.json workload_bytes [workload name, default enwik]"""
+Usage: tools/pmc_traffic.py fetch.db write.db out.json workload_bytes [workload name, default enwik] [commit the library was built from]"""
 import json
 import sqlite3
 import sys
@@ -26,7 +26,8 @@ def per_kernel(path, counter):
 fetch = per_kernel(sys.argv[1], "FETCH_SIZE")
 write = per_kernel(sys.argv[2], "WRITE_SIZE")
 out = {"workload_bytes": int(sys.argv[4]), "workload": sys.argv[5] if len(sys.argv) > 5 else "enwik", "unit": "bytes per launch",
-       "correction": "FETCH_SIZE KiB * 1024 * 2 (gfx950 half-count of wide reads) + WRITE_SIZE KiB * 1024", "kernels": {}}
+       "correction": "FETCH_SIZE KiB * 1024 * 2 (gfx950 half-count of wide reads) + WRITE_SIZE KiB * 1024",
+       "commit": sys.argv[6] if len(sys.argv) > 6 else "not recorded", "kernels": {}}
 for k in sorted(set(fetch) | set(write)):
     if "mlz::" not in k:
         continue

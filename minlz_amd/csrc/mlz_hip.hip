@@ -20,7 +20,9 @@
 #include "mlz_encode.hip.inc"
 #include "mlz_encode2.hip.inc"
 #include "mlz_decode_serial.hip.inc"
+#include "mlz_toktab.h"
 #include "mlz_decode.hip.inc"
+#include "mlz_decode_index.hip.inc"
 #include "mlz_decode_exec.hip.inc"
 #include "mlz_decode_general.hip.inc"
 #include "mlz_crc.hip.inc"
@@ -79,6 +81,7 @@ struct mlz_ctx {
     std::vector<SingleReq*> q_pending;
     bool q_leader = false;
     uint64_t q_batches = 0, q_requests = 0;  // mlz_get_counter
+    int index_passes = 0;                    // MLZ_OPT_INDEX_PASSES
     void* last_gen = nullptr;                // GenCtl of the last decode call (device memory)
     std::string err;
     std::string dev_name;
@@ -390,9 +393,10 @@ int decode_parallel(mlz_ctx* c, hipStream_t st, const uint8_t* d_src, uint8_t* d
     const size_t o_slast = o_sout + al(size_t(segs) * 4);
     const size_t o_tstart = o_slast + al(size_t(segs) * 4);
     const size_t o_rout = o_tstart + al(size_t(tiles) * sizeof(TileStart));
-    const size_t o_rlast = o_rout + al(size_t(segs) * kSegThreads * 4);
-    const size_t o_rentry = o_rlast + al(size_t(segs) * kSegThreads * 4);
-    const size_t o_sntok = o_rentry + al(size_t(segs) * kSegThreads * 4);
+    const size_t reg_words = c->index_passes ? size_t(segs) * kSegThreads : 0;   // per-region records of the three-kernel index pass only
+    const size_t o_rlast = o_rout + al(reg_words * 4);
+    const size_t o_rentry = o_rlast + al(reg_words * 4);
+    const size_t o_sntok = o_rentry + al(reg_words * 4);
     const size_t o_tpos = o_sntok + al(size_t(segs) * 4);                       // token list: a token has at least one stream byte
     const size_t o_rd = o_tpos + al(size_t(segs) * kSeg * 4);
     const size_t o_rr = o_rd + al(size_t(segs) * kSegThreads * 4);              // (per 64 tokens: indexed like the 64-byte chunks)
@@ -402,7 +406,9 @@ int decode_parallel(mlz_ctx* c, hipStream_t st, const uint8_t* d_src, uint8_t* d
     const size_t o_done = o_xcnt + al(size_t(tiles) * sizeof(GenTile));
     const size_t o_ticket = o_done + al(size_t(tiles) * 4);
     const size_t o_gen = o_ticket + 256;  // GenCtl (zeroed with the flags)
-    const size_t total = o_gen + al(sizeof(GenCtl));
+    const size_t o_sstate = o_gen + al(sizeof(GenCtl));                          // per segment: aggregate words of the index pass (all, first half; zeroed with the flags)
+    const size_t o_tok16 = o_sstate + al(size_t(segs) * 16);                    // ... and its token positions inside the segment (16 bits per stream byte; not zeroed)
+    const size_t total = o_tok16 + al(c->index_passes ? 0 : size_t(segs) * kSeg * 2);
     HIPCHK(c, c->d_dec.ensure(total));
     uint8_t* ws = c->d_dec.as<uint8_t>();
     DecBlock* dec = reinterpret_cast<DecBlock*>(ws + o_dec);
@@ -437,13 +443,14 @@ int decode_parallel(mlz_ctx* c, hipStream_t st, const uint8_t* d_src, uint8_t* d
         HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(dec_exit_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kExitLds));
         HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(dec_index_a_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kIndexLds));
         HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(dec_index_c_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kIndexCLds));
+        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(dec_index1_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kIdxLds));
         HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(dec_exec2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kExecLds));
         c->dec_attrs = true;
     }
     {
         Timer t(c, T_DEC_PARSE, st);
         // the header pass also initialises the workspace words the later passes expect (two memsets = two more launches otherwise)
-        const uint32_t n_ff = segs, n_zero = uint32_t((total - o_done) / 4);
+        const uint32_t n_ff = segs, n_zero = uint32_t((o_tok16 - o_done) / 4);
         const uint32_t hdr_grid = std::max<uint32_t>(uint32_t(n + 63) / 64, std::min<uint32_t>((std::max(n_ff, n_zero) + 255) / 256, 256u));
         hipLaunchKernelGGL(dec_header_kernel, dim3(hdr_grid), dim3(64), 0, st, d_src, blocks, dec, n, raw_body ? 1 : 0, seg_entry, n_ff,
                            reinterpret_cast<uint32_t*>(ws + o_done), n_zero);
@@ -456,13 +463,22 @@ int decode_parallel(mlz_ctx* c, hipStream_t st, const uint8_t* d_src, uint8_t* d
     }
     {
         Timer t(c, T_DEC_INDEX, st);
-        if (segs)
-            hipLaunchKernelGGL(dec_index_a_kernel, dim3(segs), dim3(kSegThreads), kIndexLds, st, d_src, blocks, seg_block, dec, seg_entry, seg_out, seg_last, rexit_tab, reg_out, reg_last, reg_entry, seg_ntok);
-        hipLaunchKernelGGL(dec_index_b_kernel, dim3(n), dim3(64), 0, st, blocks, dec, seg_out, seg_last, seg_entry, seg_ntok, n);
-        if (segs)
-            hipLaunchKernelGGL(dec_index_c_kernel, dim3(segs), dim3(kSegThreads), kIndexCLds, st, d_src, blocks, seg_block, dec, seg_entry, seg_out, seg_last,
-                               tile_start, reg_out, reg_last, reg_entry, seg_ntok, tok_pos, round_d, round_rep,
-                               jump ? &gen->n_general : nullptr);
+        if (segs && !c->index_passes) {
+            unsigned long long* sstate = reinterpret_cast<unsigned long long*>(ws + o_sstate);
+            uint16_t* tok16 = reinterpret_cast<uint16_t*>(ws + o_tok16);
+            hipLaunchKernelGGL(dec_index1_kernel, dim3(segs), dim3(kIdxThreads), kIdxLds, st, d_src, blocks, seg_block, dec, seg_entry, rexit_tab, sstate, sstate + segs, tok16);
+            hipLaunchKernelGGL(dec_index2_kernel, dim3(segs), dim3(kIdxThreads), 0, st, d_src, blocks, seg_block, dec, sstate, sstate + segs, tok16, tile_start, tok_pos,
+                               round_d, round_rep, jump ? &gen->n_general : nullptr);
+        }
+        if (c->index_passes) {   // the three-kernel form (cross-checks)
+            if (segs)
+                hipLaunchKernelGGL(dec_index_a_kernel, dim3(segs), dim3(kSegThreads), kIndexLds, st, d_src, blocks, seg_block, dec, seg_entry, seg_out, seg_last, rexit_tab, reg_out, reg_last, reg_entry, seg_ntok);
+            hipLaunchKernelGGL(dec_index_b_kernel, dim3(n), dim3(64), 0, st, blocks, dec, seg_out, seg_last, seg_entry, seg_ntok, n);
+            if (segs)
+                hipLaunchKernelGGL(dec_index_c_kernel, dim3(segs), dim3(kSegThreads), kIndexCLds, st, d_src, blocks, seg_block, dec, seg_entry, seg_out, seg_last,
+                                   tile_start, reg_out, reg_last, reg_entry, seg_ntok, tok_pos, round_d, round_rep,
+                                   jump ? &gen->n_general : nullptr);
+        }
         if (tiles) hipLaunchKernelGGL(dec_schedule_kernel, dim3(1), dim3(1024), 0, st, blocks, tile_block, dec, order, tiles, uint32_t(n),
                                       jump ? reinterpret_cast<uint32_t*>(ws + o_glist) : nullptr, reinterpret_cast<uint32_t*>(gen));
     }
@@ -857,6 +873,7 @@ int mlz_set_option(mlz_ctx* c, int opt, int64_t value) {
     case 12: c->timer_mask = uint32_t(value); return 0;  // which timers record events (bit = index of mlz_timer_name)
     case 10: c->host_group_enc = size_t(value > 0 ? value : 1) << 20; return 0;  // tuning: MiB per group of a host-pointer encode batch
     case 11: c->host_group_dec = size_t(value > 0 ? value : 1) << 20; return 0;  // ... of a decode batch
+    case 15: c->index_passes = int(value); return 0;  // decode: 1 = the index pass as three kernels (dec_index_a / _b / _c: cross-checks), 0 = dec_index_kernel (default)
     case 14: c->l2_free = int(value); return 0;  // LevelBalanced: 1 = no tile levels (ratio of the reference's L2 and better; blocks decode as general blocks)
     case 13: c->gen_force_packed = int(value); return 0;  // tests: general blocks settle through the byte-packed pool (fallback path of dec_general_kernel)
     case 9: c->gen_spin_limit = value > 0 ? uint32_t(value) : 1u; return 0;  // grid-barrier patience of the general-block pass, in polls (tests)
@@ -965,6 +982,17 @@ int mlz_debug_m2prof(unsigned long long* out) {
     if (hipMemcpyFromSymbol(out, HIP_SYMBOL(mlz::g_m2prof), sizeof(unsigned long long) * 16) != hipSuccess) return -MLZ_ERR_HIP;
     unsigned long long z[16] = {};
     if (hipMemcpyToSymbol(HIP_SYMBOL(mlz::g_m2prof), z, sizeof(z)) != hipSuccess) return -MLZ_ERR_HIP;
+    return 0;
+}
+#endif
+
+#ifdef MLZ_IDX_PROF
+// debug build only (tools/idxprof.py): per-phase time sums of dec_index_kernel; reset after reading
+int mlz_debug_idxprof(unsigned long long* out) {
+    if (hipDeviceSynchronize() != hipSuccess) return -MLZ_ERR_HIP;
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(mlz::g_idxprof), sizeof(unsigned long long) * 16) != hipSuccess) return -MLZ_ERR_HIP;
+    unsigned long long z[16] = {};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(mlz::g_idxprof), z, sizeof(z)) != hipSuccess) return -MLZ_ERR_HIP;
     return 0;
 }
 #endif

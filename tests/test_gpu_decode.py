@@ -251,6 +251,41 @@ def test_general_block_paths_agree(ctx):
         assert (v[0] == o[0]) and (v[0] == "err" or v[1] == o[1])
 
 
+def test_index_pass_forms_agree(ctx):
+    # The index pass (token list, tile starts, level conformance, block totals) exists in two forms: dec_index1 / dec_index2 (default)
+    # and the three kernels of rounds 2-3 (MLZ_OPT_INDEX_PASSES = 1).  Same output and the same verdicts on own streams of every
+    # level, on the oracle's streams (general blocks), on dense token streams (more than one stage of tokens per segment) and on
+    # mutated streams.
+    rng = np.random.default_rng(77)
+    datas = [synth.text_like(3 << 20, 4), synth.enwik_like(2 << 20, 5), synth.json_like(1 << 20, 6), bytes(rng.integers(0, 4, 300_000, dtype=np.uint8)),
+             b"ab" * 200_000 + bytes(rng.integers(0, 256, 70_000, dtype=np.uint8)) + b"xyz" * 100_000]
+    encs, want = [], []
+    for d in datas:
+        d = bytes(d)
+        for level in (-1, 1, 2):
+            encs.append(mz.Encode(d, level, ctx)); want.append(d)
+        encs.append(O.encode(d[:1 << 20], 1)); want.append(d[:1 << 20])
+        encs.append(O.encode(d[:1 << 20], 3)); want.append(d[:1 << 20])
+    mutated = []
+    for e in encs[::3]:
+        for _ in range(6):
+            m = bytearray(e)
+            pos = int(rng.integers(4, len(m)))
+            m[pos] ^= int(rng.integers(1, 256))
+            mutated.append(bytes(m))
+    results = {}
+    for passes in (0, 1):
+        ctx.set_option(mz.OPT_INDEX_PASSES, passes)
+        try:
+            assert mz.decode_batch(encs, ctx) == want
+            results[passes] = (ctx.general_blocks(), [gpu_decode_result(m, ctx) for m in mutated])
+        finally:
+            ctx.set_option(mz.OPT_INDEX_PASSES, 0)
+    assert results[0] == results[1]
+    for m, v in zip(mutated, results[0][1]):
+        assert v == oracle_decode_result(m)
+
+
 def test_own_streams_take_the_tile_path(ctx):
     # Streams of this library's encoder must be recognised as level-conformant at every level (fast pattern at level 1,
     # dense pattern at level 2); only blocks of other encoders with cross-tile copies go through the

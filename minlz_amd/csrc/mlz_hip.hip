@@ -568,6 +568,23 @@ int crc_device_locked(mlz_ctx* c, hipStream_t st, const uint8_t* d_base, const m
     return 0;
 }
 
+// Device-visible address of the host range [p, p + len) when ALL of it lies in one page-locked (pinned, registered) allocation, else 0:
+// such a destination is written by the kernels themselves.  (Both ends must lie in the SAME allocation: a buffer that merely starts
+// in one is not ours to write through.)
+uint64_t pinned_alias(const void* p, size_t len) {
+    hipPointerAttribute_t at, at_end;
+    if (!p || hipPointerGetAttributes(&at, p) != hipSuccess || at.type != hipMemoryTypeHost) { (void)hipGetLastError(); return 0; }
+    if (len > 1) {
+        const uint8_t* last = static_cast<const uint8_t*>(p) + len - 1;
+        if (hipPointerGetAttributes(&at_end, last) != hipSuccess || at_end.type != hipMemoryTypeHost ||
+            (at.devicePointer && at_end.devicePointer &&
+             static_cast<const uint8_t*>(at_end.devicePointer) - static_cast<const uint8_t*>(at.devicePointer) != ptrdiff_t(len - 1))) {
+            (void)hipGetLastError(); return 0;
+        }
+    }
+    return reinterpret_cast<uint64_t>(at.devicePointer ? at.devicePointer : const_cast<void*>(p));
+}
+
 // ---- host-pointer plumbing: pack blocks into one device buffer, run, copy back ----
 int ensure_stream_objects(mlz_ctx* c, size_t n_events, size_t pinned_bytes);  // mlz_stream.hip.inc
 
@@ -607,18 +624,8 @@ int host_batch(mlz_ctx* c, bool encode, int level, int n, const uint8_t* const* 
     std::vector<uint64_t> mirror(size_t(n), 0);
     bool use_mirror = encode || (c->decode_algo == 0 && c->general_algo == 0);
     for (int i = 0; use_mirror && i < n; i++) {
-        // (both ends of [dst[i], dst[i] + dst_cap[i]) must lie in the SAME pinned allocation: a buffer that merely starts in one is not ours to write through)
-        hipPointerAttribute_t at, at_end;
-        if (hipPointerGetAttributes(&at, dst[i]) != hipSuccess || at.type != hipMemoryTypeHost) { (void)hipGetLastError(); use_mirror = false; break; }
-        if (dst_cap[i] > 1) {
-            const uint8_t* last = dst[i] + dst_cap[i] - 1;
-            if (hipPointerGetAttributes(&at_end, last) != hipSuccess || at_end.type != hipMemoryTypeHost ||
-                (at.devicePointer && at_end.devicePointer &&
-                 static_cast<const uint8_t*>(at_end.devicePointer) - static_cast<const uint8_t*>(at.devicePointer) != ptrdiff_t(dst_cap[i] - 1))) {
-                (void)hipGetLastError(); use_mirror = false; break;
-            }
-        }
-        mirror[size_t(i)] = reinterpret_cast<uint64_t>(at.devicePointer ? at.devicePointer : static_cast<void*>(dst[i]));
+        mirror[size_t(i)] = pinned_alias(dst[i], dst_cap[i]);
+        if (!mirror[size_t(i)]) use_mirror = false;
     }
     const uint64_t* mir = use_mirror ? mirror.data() : nullptr;
     HIPCHK(c, c->d_in.ensure(in_total + 64));

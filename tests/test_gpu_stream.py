@@ -95,6 +95,30 @@ def test_stream_abi_matches_writer_mirror(ctx, level, bs):
         assert mz.stream_decode(O.stream_encode(d, lv, 1 << 20, add_index=True), ctx=ctx) == d
 
 
+def test_stream_decode_into_pinned_memory(ctx):
+    # A page-locked destination is written by the decode kernels themselves (no copy-out stage), stored chunks by the host: compressed,
+    # stored (random bytes) and reference-algorithm (general path) chunks in one stream, at an odd offset, guard bytes on both sides,
+    # good and bad CRCs.
+    import ctypes as C
+    import torch
+    from minlz_amd import _lib
+    L = _lib.lib()
+    d = synth.text_like(5_000_000, 3).tobytes() + synth.random_bytes(1_500_000, seed=8).tobytes() + synth.json_like(2 << 20, 4).tobytes()
+    for st in (mz.stream_encode(d, 1, 1 << 20, True, ctx), mz.stream_encode(d, 2, 4 << 20, False, ctx), O.stream_encode(d, 1, 1 << 20, add_index=False)):
+        src = torch.zeros(len(st) + 64, dtype=torch.uint8, pin_memory=True)
+        src.numpy()[5:5 + len(st)] = np.frombuffer(st, dtype=np.uint8)
+        dst = torch.full((len(d) + 128,), 0x5A, dtype=torch.uint8, pin_memory=True)
+        r = L.mlz_stream_decode(ctx.handle, 0, src.data_ptr() + 5, len(st), dst.data_ptr() + 33, len(d))
+        assert r == len(d)
+        h = dst.numpy()
+        assert h[33:33 + len(d)].tobytes() == d
+        assert (h[:33] == 0x5A).all() and (h[33 + len(d):] == 0x5A).all()
+        bad = bytearray(st)
+        bad[len(bad) // 2] ^= 0x10
+        src.numpy()[5:5 + len(st)] = np.frombuffer(bytes(bad), dtype=np.uint8)
+        assert L.mlz_stream_decode(ctx.handle, 0, src.data_ptr() + 5, len(st), dst.data_ptr() + 33, len(d)) < 0
+
+
 def test_stream_abi_errors(ctx):
     d = synth.text_like(3_000_000, 9).tobytes()
     st = bytearray(mz.stream_encode(d, 1, 1 << 20, True, ctx))

@@ -82,6 +82,7 @@ struct mlz_ctx {
     bool q_leader = false;
     uint64_t q_batches = 0, q_requests = 0;  // mlz_get_counter
     int index_passes = 0;                    // MLZ_OPT_INDEX_PASSES
+    int debug_stop = 0;                      // debug option 16: decode stops after the index pass (timing experiments with broken kernel variants)
     void* last_gen = nullptr;                // GenCtl of the last decode call (device memory)
     std::string err;
     std::string dev_name;
@@ -406,8 +407,9 @@ int decode_parallel(mlz_ctx* c, hipStream_t st, const uint8_t* d_src, uint8_t* d
     const size_t o_done = o_xcnt + al(size_t(tiles) * sizeof(GenTile));
     const size_t o_ticket = o_done + al(size_t(tiles) * 4);
     const size_t o_gen = o_ticket + 256;  // GenCtl (zeroed with the flags)
-    const size_t o_sstate = o_gen + al(sizeof(GenCtl));                          // per segment: aggregate words of the index pass (all, first half; zeroed with the flags)
-    const size_t o_tok16 = o_sstate + al(size_t(segs) * 16);                    // ... and its token positions inside the segment (16 bits per stream byte; not zeroed)
+    const size_t o_sstate = o_gen + al(sizeof(GenCtl));                          // per segment: aggregate words of the index pass (the segment's, then three prefixes over its quarters; zeroed with the flags)
+    const size_t o_sviol = o_sstate + al(size_t(segs) * 32);                    // ... and which level patterns its quarters' copies break (zeroed)
+    const size_t o_tok16 = o_sviol + al(size_t(segs) * 4);                    // ... and its token positions inside the segment (16 bits per stream byte; not zeroed)
     const size_t total = o_tok16 + al(c->index_passes ? 0 : size_t(segs) * kSeg * 2);
     HIPCHK(c, c->d_dec.ensure(total));
     uint8_t* ws = c->d_dec.as<uint8_t>();
@@ -467,8 +469,9 @@ int decode_parallel(mlz_ctx* c, hipStream_t st, const uint8_t* d_src, uint8_t* d
             unsigned long long* sstate = reinterpret_cast<unsigned long long*>(ws + o_sstate);
             uint16_t* tok16 = reinterpret_cast<uint16_t*>(ws + o_tok16);
             hipLaunchKernelGGL(dec_index1_kernel, dim3(segs), dim3(kIdxThreads), kIdxLds, st, d_src, blocks, seg_block, dec, seg_entry, rexit_tab, sstate, sstate + segs, tok16);
-            hipLaunchKernelGGL(dec_index2_kernel, dim3(segs), dim3(kIdxThreads), 0, st, d_src, blocks, seg_block, dec, sstate, sstate + segs, tok16, tile_start, tok_pos,
-                               round_d, round_rep, jump ? &gen->n_general : nullptr);
+            hipLaunchKernelGGL(dec_index2_kernel, dim3(2 * segs), dim3(kIdx2Threads), 0, st, d_src, blocks, seg_block, dec, sstate, sstate + segs, tok16, tile_start, tok_pos,
+                               round_d, round_rep, ws + o_sviol);
+            hipLaunchKernelGGL(dec_viol_kernel, dim3((segs + 255) / 256), dim3(256), 0, st, seg_block, ws + o_sviol, dec, jump ? &gen->n_general : nullptr, segs);
         }
         if (c->index_passes) {   // the three-kernel form (cross-checks)
             if (segs)
@@ -482,6 +485,7 @@ int decode_parallel(mlz_ctx* c, hipStream_t st, const uint8_t* d_src, uint8_t* d
         if (tiles) hipLaunchKernelGGL(dec_schedule_kernel, dim3(1), dim3(1024), 0, st, blocks, tile_block, dec, order, tiles, uint32_t(n),
                                       jump ? reinterpret_cast<uint32_t*>(ws + o_glist) : nullptr, reinterpret_cast<uint32_t*>(gen));
     }
+    if (c->debug_stop) { HIPCHK(c, hipGetLastError()); return 0; }
     {
         Timer t(c, T_DEC_EXEC, st);
         unsigned long long* prof = c->prof_on ? c->d_prof.as<unsigned long long>() : nullptr;
@@ -881,6 +885,7 @@ int mlz_set_option(mlz_ctx* c, int opt, int64_t value) {
     case 10: c->host_group_enc = size_t(value > 0 ? value : 1) << 20; return 0;  // tuning: MiB per group of a host-pointer encode batch
     case 11: c->host_group_dec = size_t(value > 0 ? value : 1) << 20; return 0;  // ... of a decode batch
     case 15: c->index_passes = int(value); return 0;  // decode: 1 = the index pass as three kernels (dec_index_a / _b / _c: cross-checks), 0 = dec_index_kernel (default)
+    case 16: c->debug_stop = int(value); return 0;  // debug: decode_batch_device returns after the index pass (out_len is not written)
     case 14: c->l2_free = int(value); return 0;  // LevelBalanced: 1 = no tile levels (ratio of the reference's L2 and better; blocks decode as general blocks)
     case 13: c->gen_force_packed = int(value); return 0;  // tests: general blocks settle through the byte-packed pool (fallback path of dec_general_kernel)
     case 9: c->gen_spin_limit = value > 0 ? uint32_t(value) : 1u; return 0;  // grid-barrier patience of the general-block pass, in polls (tests)

@@ -22,3 +22,8 @@ print("workgroups %d; microseconds per workgroup (thread 0's clock):" % n)
 for i, nm in enumerate(names):
     print("  %-18s %7.2f" % (nm, out[i] / n / 100.0))
 print("  %-18s %7.2f" % ("sum", sum(out[i] for i in range(4)) / n / 100.0))
+n2 = out[14]
+if n2:
+    print("phase 2, workgroups %d; microseconds per workgroup (thread 0's clock):" % n2)
+    for i, nm in ((8, "descriptors, first requests, look-back"), (9, "barrier"), (10, "base, set-up"), (11, "token rounds")):
+        print("  %-40s %7.2f" % (nm, out[i] / n2 / 100.0))

@@ -91,6 +91,7 @@ struct mlz_ctx {
     // Block descriptors on the device, one set per kind of call (0 encode / crc, 1 decode): an encode and a decode that
     // alternate (a Writer next to a Reader, bench.py) each find their descriptors already uploaded.
     DevBuf d_blocks_k[2], d_tile_block_k[2], d_seg_block_k[2];
+    DevBuf d_place;                          // mlz_stream_encode into pinned memory: placement descriptors
     std::vector<BlockInfo> h_blocks, h_blocks_prev_k[2];
     int dk = 0;  // kind of the call in progress
     DevBuf& d_blocks_cur() { return d_blocks_k[dk]; }
@@ -747,7 +748,7 @@ void mlz_destroy(mlz_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
-    for (DevBuf* b : {&c->d_crc, &c->d_crc_tabs, &c->d_crc_tiles, &c->d_prof, &c->d_blocks_k[0], &c->d_blocks_k[1], &c->d_tile_block_k[0], &c->d_tile_block_k[1], &c->d_seg_block_k[0], &c->d_seg_block_k[1], &c->d_scratch, &c->d_tile_size, &c->d_tile_out, &c->d_flags, &c->d_far, &c->d_recs, &c->d_piece_cnt, &c->d_dec, &c->d_idx, &c->d_in, &c->d_out, &c->d_len})
+    for (DevBuf* b : {&c->d_place, &c->d_crc, &c->d_crc_tabs, &c->d_crc_tiles, &c->d_prof, &c->d_blocks_k[0], &c->d_blocks_k[1], &c->d_tile_block_k[0], &c->d_tile_block_k[1], &c->d_seg_block_k[0], &c->d_seg_block_k[1], &c->d_scratch, &c->d_tile_size, &c->d_tile_out, &c->d_flags, &c->d_far, &c->d_recs, &c->d_piece_cnt, &c->d_dec, &c->d_idx, &c->d_in, &c->d_out, &c->d_len})
         b->release();
     if (c->pinned) (void)hipHostFree(c->pinned);
     if (c->pinned2) (void)hipHostFree(c->pinned2);

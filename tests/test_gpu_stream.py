@@ -119,6 +119,28 @@ def test_stream_decode_into_pinned_memory(ctx):
         assert L.mlz_stream_decode(ctx.handle, 0, src.data_ptr() + 5, len(st), dst.data_ptr() + 33, len(d)) < 0
 
 
+def test_stream_encode_into_pinned_memory(ctx):
+    # A page-locked destination of mlz_stream_encode: headers by the host, chunk bodies by stream_place_kernel — the same bytes as into
+    # pageable memory, nothing outside [dst, dst + returned length) touched except inside the bound; compressed and stored chunks, index.
+    import ctypes as C
+    import torch
+    from minlz_amd import _lib
+    L = _lib.lib()
+    d = synth.text_like(9_000_000, 13).tobytes() + synth.random_bytes(2_500_000, seed=9).tobytes() + synth.json_like(3 << 20, 14).tobytes() + b"tail"
+    src = torch.zeros(len(d) + 64, dtype=torch.uint8, pin_memory=True)
+    src.numpy()[7:7 + len(d)] = np.frombuffer(d, dtype=np.uint8)
+    for level, bs, flags in ((1, 1 << 20, 1), (2, 8 << 20, 0), (0, 64 << 10, 1)):
+        want = mz.stream_encode(d, level, bs, bool(flags), ctx)
+        cap = L.mlz_stream_bound(len(d), bs, flags)
+        dst = torch.full((cap + 96,), 0x5A, dtype=torch.uint8, pin_memory=True)
+        r = L.mlz_stream_encode(ctx.handle, level, bs, flags, src.data_ptr() + 7, len(d), dst.data_ptr() + 19, cap)
+        assert r == len(want)
+        h = dst.numpy()
+        assert h[19:19 + r].tobytes() == want
+        assert (h[:19] == 0x5A).all() and (h[19 + cap:] == 0x5A).all()
+        assert O.stream_decode(want, len(d)) == d
+
+
 def test_stream_abi_errors(ctx):
     d = synth.text_like(3_000_000, 9).tobytes()
     st = bytearray(mz.stream_encode(d, 1, 1 << 20, True, ctx))

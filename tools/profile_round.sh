@@ -15,4 +15,4 @@ timeout 300 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_${tag}_f8 -o 
 python $R/tools/rocpd_summary.py $R/gpurun_out/prof_${tag}_f8/t_results.db > $R/gpurun_out/${tag}_foreign_kernel_stats.txt
 BLOCK=2097152 timeout 300 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_${tag}_f2 -o t -- python $R/tools/foreign_time.py enwik 100 > $R/gpurun_out/${tag}_foreign_2MiB.log 2>&1
 python $R/tools/rocpd_summary.py $R/gpurun_out/prof_${tag}_f2/t_results.db > $R/gpurun_out/${tag}_foreign_2MiB_kernel_stats.txt
-tail -2 $R/gpurun_out/${tag}_foreign_8MiB.log $R/gpurun_out/${tag}_foreign_2MiB.log
+tail -n 2 $R/gpurun_out/${tag}_foreign_8MiB.log $R/gpurun_out/${tag}_foreign_2MiB.log

@@ -18,7 +18,12 @@ st = torch.cuda.current_stream(dev).cuda_stream
 ctx.encode_batch_device(st, 1, src.data_ptr(), enc.data_ptr(), desc, enc_len.data_ptr()); torch.cuda.synchronize()
 lens = enc_len.cpu().tolist()
 dec = torch.empty(S + 256, dtype=torch.uint8, device=dev); dec_len = torch.zeros(nblk, dtype=torch.int64, device=dev)
-ddesc = (BlockDesc * nblk)(*[BlockDesc(i * stride, lens[i], i * BLOCK, blk_len[i]) for i in range(nblk)])
+SHIFT = int(os.environ.get('SHIFT', '0'))   # the blocks moved by this many bytes (alignment experiments: the token stream starts 5 bytes into a block)
+if SHIFT:
+    enc2 = torch.zeros(nblk * stride + 64, dtype=torch.uint8, device=dev)
+    for i in range(nblk): enc2[i * stride + SHIFT:i * stride + SHIFT + lens[i]] = enc[i * stride:i * stride + lens[i]]
+    enc = enc2
+ddesc = (BlockDesc * nblk)(*[BlockDesc(i * stride + SHIFT, lens[i], i * BLOCK, blk_len[i]) for i in range(nblk)])
 ctx.set_option(16, 1)
 ctx.set_option(mz.OPT_TIMING, 1)
 acc = {}

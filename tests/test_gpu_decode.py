@@ -142,6 +142,30 @@ def test_dense_token_streams(ctx):
         assert code == 0 and got == want, kind
 
 
+def test_literal_runs_longer_than_a_region_group(ctx):
+    # The index pass chains a segment's 64-byte regions with 15 lanes that start at guessed positions and must meet each other inside a
+    # group of 8 regions (512 bytes); literal runs of 600 .. 9000 bytes of token-like bytes keep them apart, so one thread chains the
+    # segment instead, and the runs cross segment boundaries (entries deep inside a segment: the chain kernel's slow exits).  Literal
+    # bytes are drawn from the values that long-literal and copy3 tags have, so the parse from a wrong start derails as far as it can.
+    rng = np.random.default_rng(23)
+    taggy = np.array([0xE8, 0xF0, 0xF8, 0xFF, 0x07, 0x0F, 0xFB, 0x02, 0x01, 0x00], dtype=np.uint8)
+    for trial in range(3):
+        tok = bytearray()
+        out = bytearray()
+        while len(out) < 1_500_000:
+            n = int(rng.integers(600, 9000 if trial else 1400))
+            lit = bytes(taggy[rng.integers(0, len(taggy), n)]) if trial != 2 else bytes(rng.integers(0, 256, n, dtype=np.uint8))
+            tok += O.emit_literal(lit); out += lit
+            for _ in range(int(rng.integers(1, 40))):
+                off = int(rng.integers(1, min(len(out), 70000))); ln = int(rng.integers(4, 60))
+                tok += O.emit_copy(off, ln)
+                for _ in range(ln): out.append(out[len(out) - off])
+        code, want = O.decode_body(bytes(tok), len(out))
+        assert code == 0 and want == bytes(out)
+        code, got = mz.decode_block(bytes(tok), len(out), ctx)
+        assert code == 0 and got == want, trial
+
+
 def test_decode_block_corrupt_verdicts(ctx):
     # minLZDecode contract (decode.go:178): 0 ok / 1 corrupt, same as the oracle, on mutated streams
     d = synth.text_like(200000, 9)

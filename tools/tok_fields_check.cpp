@@ -1,15 +1,16 @@
 // Checks the table form of the token decode (minlz_amd/csrc/mlz_toktab.h: tok_entry / tok_adv / tok_olen / tok_lit / tok_off) against
 // decode_tok: every value of a token's first two bytes x 2^16 random values + the all-zero / all-one patterns of the six bytes behind them.
-// build + run: g++ -O2 -o /tmp/tfc tools/tok_fields_check.cpp && /tmp/tfc   (a few seconds)
+// build + run: g++ -O2 -o /tmp/tfc tools/tok_fields_check.cpp && /tmp/tfc [stride]   (all values: a minute; tests/test_toktab.py runs every 41st)
 #include <cstdio>
 #include <cstdlib>
 #include "../minlz_amd/csrc/mlz_toktab.h"
 using namespace mlz;
-int main() {
+int main(int argc, char** argv) {
+    const uint32_t stride = argc > 1 ? uint32_t(atoi(argv[1])) : 1;   // every stride-th value of the first two bytes (tests: a quick pass)
     uint32_t tab[256];
     for (uint32_t b = 0; b < 256; b++) tab[b] = tok_entry(b);
     uint64_t rng = 0x9e3779b97f4a7c15ull, bad = 0, n = 0;
-    for (uint32_t b01 = 0; b01 < 65536; b01++) {
+    for (uint32_t b01 = 0; b01 < 65536; b01 += stride ? stride : 1) {
         for (uint32_t r = 0; r < 65536 + 4; r++) {
             uint64_t hi;
             if (r == 65536) hi = 0; else if (r == 65537) hi = ~0ull; else if (r == 65538) hi = 0x0000ffffffull; else if (r == 65539) hi = 0xffffff000000ull;

@@ -138,7 +138,7 @@ int64_t mlz_stream_decode(mlz_ctx* ctx, uint32_t flags, const uint8_t* src, size
 #define MLZ_OPT_L2_FREE 14     /* LevelBalanced: 1 (default) = no tile levels — a copy may read any earlier tile of its window: the ratio of the
                                 * reference's encode_l2.go and better (0.93 - 1.05 x its restatement), and the blocks decode, like the reference's own,
                                 * through the general-block path; 0 = the four-level tile pattern of rounds 1-3 (1.08 - 1.09 x, level-scheduled decode) */
-#define MLZ_OPT_INDEX_PASSES 15 /* decode, cross-checks: 1 = the index pass as the three kernels of rounds 2-3 instead of dec_index_kernel (default 0) */
+#define MLZ_OPT_INDEX_PASSES 15 /* decode, cross-checks: 1 = the index pass as the three kernels of rounds 2-3 instead of dec_index1 / dec_index2 / dec_viol (default 0) */
 /* (debug, timing experiments: option 16 = 1 makes mlz_decode_batch_device return after the index pass, without output) */
 #define MLZ_OPT_GEN_SPIN 9     /* patience of the general-block decode with a tile's ready flag, in polls (~0.3 us each; default 2^24); tests */
 #define MLZ_OPT_GEN_PACKED 13  /* tests: 1 = general blocks settle through the byte-packed pool (the fallback of tiles whose slots do not fit) */

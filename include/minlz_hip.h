@@ -98,9 +98,15 @@ int mlz_decode_batch(mlz_ctx* ctx, int n_blocks, const uint8_t* const* src, cons
  * mlz_encode / mlz_decode would have returned for block i.  `desc` is a host array (copied).
  * A context owns ONE workspace: calls issued on different streams are ordered on the device (each waits for the
  * previous call's last kernel through an event), so they are safe but do not overlap; use one context per stream
- * for concurrency.  The workspace grows to the largest batch seen and is kept: decode needs about 6.5 bytes per
- * compressed input byte (region exits, the token list — sized for one token per stream byte), encode about 3 bytes per
- * input byte plus 1.5 MiB of far tables per 8 MiB block. */
+ * for concurrency.
+ * Workspace: a batch runs in internal groups of about 512 MiB of uncompressed data (MLZ_OPT_DEVICE_GROUP; at least one block per group;
+ * throughput is flat from 64 blocks of 8 MiB on), one after the other on `stream`, so the workspace is bounded by the group, not by the
+ * batch.  It grows to the largest group seen and is kept (mlz_get_counter 3 / 4 report it).  Per group, decode holds about 7 bytes per
+ * compressed byte (region exits, the token list — sized for one token per stream byte —, 16-bit token positions) and, for the
+ * general-block pass (blocks of other encoders, LevelBalanced's own), 3 bytes per output byte + 8 bytes per stream byte: about 10 bytes
+ * per output byte on text-like data, 5.3 GB for a full group.  Encode holds about 3.3 bytes per input byte (token records, piece
+ * scratch) plus the far tables (1.5 MiB per 8 MiB block, LevelBalanced 8 MiB): about 3 GB per group.  If the general pass's buffers
+ * cannot be allocated, general blocks decode on the exec pass's tile chain instead (slow, correct; mlz_get_counter 5 counts such calls). */
 int mlz_encode_batch_device(mlz_ctx* ctx, void* stream, int level, const uint8_t* d_src, uint8_t* d_dst,
                             const mlz_block_desc* desc, int n_blocks, int64_t* d_out_len);
 int mlz_decode_batch_device(mlz_ctx* ctx, void* stream, const uint8_t* d_src, uint8_t* d_dst,
@@ -138,6 +144,7 @@ int64_t mlz_stream_decode(mlz_ctx* ctx, uint32_t flags, const uint8_t* src, size
 #define MLZ_OPT_L2_FREE 14     /* LevelBalanced: 1 (default) = no tile levels — a copy may read any earlier tile of its window: the ratio of the
                                 * reference's encode_l2.go and better (0.93 - 1.05 x its restatement), and the blocks decode, like the reference's own,
                                 * through the general-block path; 0 = the four-level tile pattern of rounds 1-3 (1.08 - 1.09 x, level-scheduled decode) */
+#define MLZ_OPT_DEVICE_GROUP 17 /* MiB of uncompressed data per internal group of a device batch (default 512): bounds the workspace */
 #define MLZ_OPT_INDEX_PASSES 15 /* decode, cross-checks: 1 = the index pass as the three kernels of rounds 2-3 instead of dec_index1 / dec_index2 / dec_viol (default 0) */
 /* (debug, timing experiments: option 16 = 1 makes mlz_decode_batch_device return after the index pass, without output) */
 #define MLZ_OPT_GEN_SPIN 9     /* patience of the general-block decode with a tile's ready flag, in polls (~0.3 us each; default 2^24); tests */
@@ -155,7 +162,9 @@ const char* mlz_timer_name(int idx);
  * reader.go:830-859 — are run as one batched launch.  which: 0 = batches run, 1 = requests served.
  * which = 2: blocks of the last decode call that matched no tile-level pattern of this library's encoder and went through the
  * general-block path (mlz_decode_general.hip.inc): the reference's own blocks, and this library's LevelBalanced ones.
- * which = 3 / 4: bytes of device workspace the context holds for encoding / decoding (grow-only: the high-water mark so far). */
+ *            (of a batch that ran as several internal groups: those of its last group).
+ * which = 3 / 4: bytes of device workspace the context holds for encoding / decoding (grow-only: the high-water mark so far).
+ * which = 5: decode calls whose general blocks fell back to the tile chain because the general pass's buffers could not be allocated. */
 int64_t mlz_get_counter(mlz_ctx* ctx, int which);
 
 #ifdef __cplusplus

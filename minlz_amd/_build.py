@@ -6,7 +6,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc", "mlz_hip.hip")
 SO = os.path.join(HERE, "libminlz_hip.so")
-DEPS = ["mlz_hip.hip", "mlz_format.h", "mlz_kernels.h", "mlz_encode.hip.inc", "mlz_encode2.hip.inc", "mlz_decode.hip.inc", "mlz_decode_exec.hip.inc", "mlz_decode_general.hip.inc", "mlz_decode_serial.hip.inc", "mlz_crc.hip.inc", "mlz_stream.hip.inc"]
+CSRC = os.path.join(HERE, "csrc")
 
 
 def hipcc():
@@ -20,7 +20,8 @@ def stale():
     if not os.path.exists(SO):
         return True
     t = os.path.getmtime(SO)
-    paths = [os.path.join(HERE, "csrc", d) for d in DEPS] + [os.path.join(os.path.dirname(HERE), "include", "minlz_hip.h")]
+    # every file under csrc/ is part of the one translation unit (mlz_hip.hip includes the rest)
+    paths = [os.path.join(CSRC, d) for d in sorted(os.listdir(CSRC))] + [os.path.join(os.path.dirname(HERE), "include", "minlz_hip.h")]
     return any(os.path.getmtime(p) > t for p in paths)
 
 

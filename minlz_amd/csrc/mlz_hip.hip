@@ -98,10 +98,16 @@ struct mlz_ctx {
     DevBuf& d_tile_block_cur() { return d_tile_block_k[dk]; }
     DevBuf& d_seg_block_cur() { return d_seg_block_k[dk]; }
     std::vector<uint32_t> h_tile_block, h_seg_block;
-    void* pinned = nullptr;
-    size_t pinned_cap = 0;
-    hipEvent_t upload_done = nullptr;
-    bool upload_pending = false;
+    // descriptor staging: two page-locked buffers used in turn, so that the upload of one internal group (device_group below) does not make
+    // the host wait for the kernels of the group before it
+    void* pinned_k[2] = {nullptr, nullptr};
+    size_t pinned_cap_k[2] = {0, 0};
+    hipEvent_t upload_done_k[2] = {nullptr, nullptr};
+    bool upload_pending_k[2] = {false, false};
+    int up_slot = 0;
+    // Device batches run in internal groups of about this many bytes of uncompressed data (option MLZ_OPT_DEVICE_GROUP): the workspace is then
+    // bounded by the group, not by the batch (round 4: 42 GB of decode workspace for a 4 GiB batch).  Throughput is flat from 64 x 8 MiB blocks on.
+    size_t device_group = size_t(512) << 20;
     // One workspace serves every call on this context: a call on another stream first waits (on the device) for the
     // previous call's last launch, so descriptors, scratch and flags are never shared by two calls in flight.
     hipEvent_t ws_done = nullptr;
@@ -117,6 +123,7 @@ struct mlz_ctx {
     uint32_t gen_spin_limit = 1u << 24;  // role S's patience with a tile's ready flag, in polls (~0.3 us each): ~5 s
     int n_cus = 0;
     int l2_free = 1;           // option 14 (default on): LevelBalanced without the tile-level constraint (better ratio; its blocks decode through the general path)
+    uint64_t gen_fallbacks = 0;  // decode calls whose general blocks took the tile chain because the general pass's buffers could not be allocated (mlz_get_counter 5)
     int gen_force_packed = 0;  // tests: every tile of a general block takes the byte-packed pool (the fallback path)
     // host-pointer staging
     DevBuf d_in, d_out, d_len, d_crc, d_crc_tabs, d_crc_tiles;
@@ -134,13 +141,14 @@ struct mlz_ctx {
     int debug_status = 0;
     bool prof_on = false;
     DevBuf d_prof;
-    hipEvent_t ev[T_COUNT][2] = {};
-    bool ev_used[T_COUNT] = {};
-    // timing == 2: a ring of event pairs per timer, resolved kTimerRing uses later (long complete by then), so
-    // reading the clock never stalls the caller and launches can run ahead of the device
+    // A ring of event pairs per timer, resolved kTimerRing uses later (long complete by then), so reading the clock never stalls the caller and
+    // launches can run ahead of the device.  A device batch runs as one or more internal groups, each firing the timers: acc_ms sums them and
+    // ev_calls counts the API calls a timer fired in.  timing == 1 restarts a timer's sum at the first firing of a new call (the last call's
+    // times), timing == 2 keeps the sum over all calls since it was enabled (get_timers divides by the calls).
     static constexpr int kTimerRing = 8;
     hipEvent_t evr[T_COUNT][kTimerRing][2] = {};
-    uint64_t ev_cnt[T_COUNT] = {}, ev_res[T_COUNT] = {};
+    uint64_t ev_cnt[T_COUNT] = {}, ev_res[T_COUNT] = {}, ev_calls[T_COUNT] = {}, ev_last_call[T_COUNT] = {};
+    uint64_t call_seq = 0;
     double acc_ms[T_COUNT] = {};
     void resolve_one(int id) {
         const int slot = int(ev_res[id] % kTimerRing);
@@ -164,18 +172,23 @@ namespace {
 struct Timer {
     mlz_ctx* c; int id; hipStream_t s;
     bool on;
-    Timer(mlz_ctx* c_, int id_, hipStream_t s_) : c(c_), id(id_), s(s_), on(((c_->timer_mask >> id_) & 1) != 0) {
+    Timer(mlz_ctx* c_, int id_, hipStream_t s_) : c(c_), id(id_), s(s_), on(c_->timing != 0 && ((c_->timer_mask >> id_) & 1) != 0) {
         if (!on) return;
-        if (c->timing == 1) { (void)hipEventRecord(c->ev[id][0], s); }
-        else if (c->timing == 2) {
-            while (c->ev_cnt[id] - c->ev_res[id] >= uint64_t(mlz_ctx::kTimerRing)) c->resolve_one(id);
-            (void)hipEventRecord(c->evr[id][c->ev_cnt[id] % mlz_ctx::kTimerRing][0], s);
+        if (c->ev_last_call[id] != c->call_seq) {   // first firing in this API call
+            c->ev_last_call[id] = c->call_seq;
+            if (c->timing == 1) {
+                while (c->ev_res[id] < c->ev_cnt[id]) c->resolve_one(id);
+                c->acc_ms[id] = 0; c->ev_calls[id] = 0;
+            }
+            c->ev_calls[id]++;
         }
+        while (c->ev_cnt[id] - c->ev_res[id] >= uint64_t(mlz_ctx::kTimerRing)) c->resolve_one(id);
+        (void)hipEventRecord(c->evr[id][c->ev_cnt[id] % mlz_ctx::kTimerRing][0], s);
     }
     ~Timer() {
         if (!on) return;
-        if (c->timing == 1) { (void)hipEventRecord(c->ev[id][1], s); c->ev_used[id] = true; }
-        else if (c->timing == 2) { (void)hipEventRecord(c->evr[id][c->ev_cnt[id] % mlz_ctx::kTimerRing][1], s); c->ev_cnt[id]++; }
+        (void)hipEventRecord(c->evr[id][c->ev_cnt[id] % mlz_ctx::kTimerRing][1], s);
+        c->ev_cnt[id]++;
     }
 };
 
@@ -228,34 +241,52 @@ int upload_blocks(mlz_ctx* c, hipStream_t st, const mlz_block_desc* desc, int n,
         for (uint32_t t = 0; t < c->h_blocks[i].n_segs; t++) c->h_seg_block[c->h_blocks[i].first_seg + t] = uint32_t(i);
     }
     const size_t nb = sizeof(BlockInfo) * n, nt = sizeof(uint32_t) * tiles, ns = sizeof(uint32_t) * segs;
-    if (c->upload_pending) { HIPCHK(c, hipEventSynchronize(c->upload_done)); c->upload_pending = false; }
-    if (nb + nt + ns > c->pinned_cap) {
-        if (c->pinned) HIPCHK(c, hipHostFree(c->pinned));
-        c->pinned = nullptr;
-        c->pinned_cap = (nb + nt + ns) * 2 + 4096;
-        HIPCHK(c, hipHostMalloc(&c->pinned, c->pinned_cap, hipHostMallocDefault));
+    const int sl = (c->up_slot ^= 1);
+    if (c->upload_pending_k[sl]) { HIPCHK(c, hipEventSynchronize(c->upload_done_k[sl])); c->upload_pending_k[sl] = false; }
+    if (nb + nt + ns > c->pinned_cap_k[sl]) {
+        if (c->pinned_k[sl]) HIPCHK(c, hipHostFree(c->pinned_k[sl]));
+        c->pinned_k[sl] = nullptr;
+        c->pinned_cap_k[sl] = (nb + nt + ns) * 2 + 4096;
+        HIPCHK(c, hipHostMalloc(&c->pinned_k[sl], c->pinned_cap_k[sl], hipHostMallocDefault));
     }
+    char* pin = static_cast<char*>(c->pinned_k[sl]);
     HIPCHK(c, c->d_blocks_cur().ensure(nb + 64));
     HIPCHK(c, c->d_tile_block_cur().ensure(nt + 64));
     HIPCHK(c, c->d_seg_block_cur().ensure(ns + 64));
-    std::memcpy(c->pinned, c->h_blocks.data(), nb);
-    std::memcpy(static_cast<char*>(c->pinned) + nb, c->h_tile_block.data(), nt);
-    std::memcpy(static_cast<char*>(c->pinned) + nb + nt, c->h_seg_block.data(), ns);
-    if (nb) HIPCHK(c, hipMemcpyAsync(c->d_blocks_cur().p, c->pinned, nb, hipMemcpyHostToDevice, st));
-    if (nt) HIPCHK(c, hipMemcpyAsync(c->d_tile_block_cur().p, static_cast<char*>(c->pinned) + nb, nt, hipMemcpyHostToDevice, st));
-    if (ns) HIPCHK(c, hipMemcpyAsync(c->d_seg_block_cur().p, static_cast<char*>(c->pinned) + nb + nt, ns, hipMemcpyHostToDevice, st));
-    HIPCHK(c, hipEventRecord(c->upload_done, st));
-    c->upload_pending = true;
+    std::memcpy(pin, c->h_blocks.data(), nb);
+    std::memcpy(pin + nb, c->h_tile_block.data(), nt);
+    std::memcpy(pin + nb + nt, c->h_seg_block.data(), ns);
+    if (nb) HIPCHK(c, hipMemcpyAsync(c->d_blocks_cur().p, pin, nb, hipMemcpyHostToDevice, st));
+    if (nt) HIPCHK(c, hipMemcpyAsync(c->d_tile_block_cur().p, pin + nb, nt, hipMemcpyHostToDevice, st));
+    if (ns) HIPCHK(c, hipMemcpyAsync(c->d_seg_block_cur().p, pin + nb + nt, ns, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipEventRecord(c->upload_done_k[sl], st));
+    c->upload_pending_k[sl] = true;
     prev = c->h_blocks;
     return 0;
 }
 
-int encode_device_locked(mlz_ctx* c, hipStream_t st, int level, const uint8_t* d_src, uint8_t* d_dst, const mlz_block_desc* desc, int n,
-                         int64_t* d_out_len, bool with_header, const uint64_t* mirror = nullptr) {
-    if (!valid_level(level)) return -MLZ_ERR_INVALID_LEVEL;
-    if (n <= 0) return 0;
-    HIPCHK(c, hipSetDevice(c->device));
-    WorkspaceOrder order(c, st);
+// Blocks [0, n) of a device batch cut into consecutive groups of about c->device_group bytes of uncompressed data (at least one block each):
+// calls fn(first, count) per group.  The groups run one after the other on the call's stream and share the workspace.
+template <class F> int for_each_group(mlz_ctx* c, const mlz_block_desc* desc, int n, bool by_dst, F fn) {
+    int b0 = 0;
+    while (b0 < n) {
+        uint64_t bytes = 0;
+        int b1 = b0;
+        while (b1 < n) {
+            const uint64_t span = std::min<uint64_t>(by_dst ? desc[b1].dst_cap : desc[b1].src_len, kMaxBlockSize);
+            if (b1 > b0 && bytes + span > c->device_group) break;
+            bytes += span;
+            b1++;
+        }
+        const int r = fn(b0, b1 - b0);
+        if (r) return r;
+        b0 = b1;
+    }
+    return 0;
+}
+
+int encode_device_group(mlz_ctx* c, hipStream_t st, int level, const uint8_t* d_src, uint8_t* d_dst, const mlz_block_desc* desc, int n,
+                        int64_t* d_out_len, bool with_header, const uint64_t* mirror) {
     uint32_t tiles = 0;
     int r = upload_blocks(c, st, desc, n, false, &tiles, nullptr, mirror);
     if (r) return r;
@@ -437,8 +468,14 @@ int decode_parallel(mlz_ctx* c, hipStream_t st, const uint8_t* d_src, uint8_t* d
     // output byte, 8 B per possible token for the external entries — is affordable (<= 64 GiB) and the current exec pass is in use.
     const size_t map_bytes = (size_t(tiles) << kTileLog) * 3;   // maps, then pools
     const size_t ext_entries = (size_t(segs) << kSegLog) + size_t(tiles) * kExtPerTile + 64 * size_t(n);
-    const bool jump = c->general_algo == 0 && c->decode_algo == 0 && tiles > 0 && map_bytes + ext_entries * sizeof(ExtEnt) <= (size_t(64) << 30);
-    if (jump) HIPCHK(c, c->d_idx.ensure(map_bytes + ext_entries * sizeof(ExtEnt) + 256));
+    bool jump = c->general_algo == 0 && c->decode_algo == 0 && tiles > 0;
+    if (jump && c->d_idx.ensure(map_bytes + ext_entries * sizeof(ExtEnt) + 256) != hipSuccess) {
+        // The device cannot hold the pass's buffers (another tenant's memory, a small part): not a reason to fail the call — general blocks
+        // then stay on the exec pass's tile chain, which needs none (slow, correct).  Counted, so that a caller can see it: mlz_get_counter(ctx, 5).
+        (void)hipGetLastError();
+        c->gen_fallbacks++;
+        jump = false;
+    }
     const BlockInfo* blocks = c->d_blocks_cur().as<BlockInfo>();
     const uint32_t* tile_block = c->d_tile_block_cur().as<uint32_t>();
     const uint32_t* seg_block = c->d_seg_block_cur().as<uint32_t>();
@@ -522,11 +559,20 @@ int decode_parallel(mlz_ctx* c, hipStream_t st, const uint8_t* d_src, uint8_t* d
     return 0;
 }
 
-int decode_device_locked(mlz_ctx* c, hipStream_t st, const uint8_t* d_src, uint8_t* d_dst, const mlz_block_desc* desc, int n, int64_t* d_out_len,
-                         bool raw_body, const uint64_t* mirror = nullptr) {
+int encode_device_locked(mlz_ctx* c, hipStream_t st, int level, const uint8_t* d_src, uint8_t* d_dst, const mlz_block_desc* desc, int n,
+                         int64_t* d_out_len, bool with_header, const uint64_t* mirror = nullptr) {
+    if (!valid_level(level)) return -MLZ_ERR_INVALID_LEVEL;
     if (n <= 0) return 0;
     HIPCHK(c, hipSetDevice(c->device));
     WorkspaceOrder order(c, st);
+    c->call_seq++;
+    return for_each_group(c, desc, n, false, [&](int b0, int cnt) {
+        return encode_device_group(c, st, level, d_src, d_dst, desc + b0, cnt, d_out_len + b0, with_header, mirror ? mirror + b0 : nullptr);
+    });
+}
+
+int decode_device_group(mlz_ctx* c, hipStream_t st, const uint8_t* d_src, uint8_t* d_dst, const mlz_block_desc* desc, int n, int64_t* d_out_len,
+                        bool raw_body, const uint64_t* mirror) {
     if (c->decode_algo == 1) {
         uint32_t tiles = 0;
         int r = upload_blocks(c, st, desc, n, true, &tiles);
@@ -539,10 +585,22 @@ int decode_device_locked(mlz_ctx* c, hipStream_t st, const uint8_t* d_src, uint8
     return decode_parallel(c, st, d_src, d_dst, desc, n, d_out_len, raw_body, mirror);
 }
 
+int decode_device_locked(mlz_ctx* c, hipStream_t st, const uint8_t* d_src, uint8_t* d_dst, const mlz_block_desc* desc, int n, int64_t* d_out_len,
+                         bool raw_body, const uint64_t* mirror = nullptr) {
+    if (n <= 0) return 0;
+    HIPCHK(c, hipSetDevice(c->device));
+    WorkspaceOrder order(c, st);
+    c->call_seq++;
+    return for_each_group(c, desc, n, true, [&](int b0, int cnt) {
+        return decode_device_group(c, st, d_src, d_dst, desc + b0, cnt, d_out_len + b0, raw_body, mirror ? mirror + b0 : nullptr);
+    });
+}
+
 int crc_device_locked(mlz_ctx* c, hipStream_t st, const uint8_t* d_base, const mlz_block_desc* desc, int n, uint32_t* d_out) {
     if (n <= 0) return 0;
     HIPCHK(c, hipSetDevice(c->device));
     WorkspaceOrder order(c, st);
+    c->call_seq++;
     uint32_t tiles = 0;
     int r = upload_blocks(c, st, desc, n, false, &tiles, nullptr, nullptr, true);
     if (r) return r;
@@ -735,11 +793,9 @@ int mlz_init(int device, mlz_ctx** out) {
     }
     if (c->n_cus <= 0) c->n_cus = 64;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return -MLZ_ERR_HIP; }
-    if (hipEventCreateWithFlags(&c->upload_done, hipEventDisableTiming) != hipSuccess) { delete c; return -MLZ_ERR_HIP; }
+    for (int k = 0; k < 2; k++)
+        if (hipEventCreateWithFlags(&c->upload_done_k[k], hipEventDisableTiming) != hipSuccess) { delete c; return -MLZ_ERR_HIP; }
     if (hipEventCreateWithFlags(&c->ws_done, hipEventDisableTiming) != hipSuccess) { delete c; return -MLZ_ERR_HIP; }
-    for (int i = 0; i < T_COUNT; i++)
-        for (int k = 0; k < 2; k++)
-            if (hipEventCreate(&c->ev[i][k]) != hipSuccess) { delete c; return -MLZ_ERR_HIP; }
     *out = c;
     return 0;
 }
@@ -750,7 +806,7 @@ void mlz_destroy(mlz_ctx* c) {
     (void)hipDeviceSynchronize();
     for (DevBuf* b : {&c->d_place, &c->d_crc, &c->d_crc_tabs, &c->d_crc_tiles, &c->d_prof, &c->d_blocks_k[0], &c->d_blocks_k[1], &c->d_tile_block_k[0], &c->d_tile_block_k[1], &c->d_seg_block_k[0], &c->d_seg_block_k[1], &c->d_scratch, &c->d_tile_size, &c->d_tile_out, &c->d_flags, &c->d_far, &c->d_recs, &c->d_piece_cnt, &c->d_dec, &c->d_idx, &c->d_in, &c->d_out, &c->d_len})
         b->release();
-    if (c->pinned) (void)hipHostFree(c->pinned);
+    for (int k = 0; k < 2; k++) if (c->pinned_k[k]) (void)hipHostFree(c->pinned_k[k]);
     if (c->pinned2) (void)hipHostFree(c->pinned2);
     if (c->s_in) (void)hipStreamDestroy(c->s_in);
     if (c->s_out) (void)hipStreamDestroy(c->s_out);
@@ -759,10 +815,7 @@ void mlz_destroy(mlz_ctx* c) {
         for (int k = 0; k < mlz_ctx::kTimerRing; k++)
             for (int e = 0; e < 2; e++)
                 if (c->evr[i][k][e]) (void)hipEventDestroy(c->evr[i][k][e]);
-    for (int i = 0; i < T_COUNT; i++)
-        for (int k = 0; k < 2; k++)
-            if (c->ev[i][k]) (void)hipEventDestroy(c->ev[i][k]);
-    if (c->upload_done) (void)hipEventDestroy(c->upload_done);
+    for (int k = 0; k < 2; k++) if (c->upload_done_k[k]) (void)hipEventDestroy(c->upload_done_k[k]);
     if (c->ws_done) (void)hipEventDestroy(c->ws_done);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -885,8 +938,9 @@ int mlz_set_option(mlz_ctx* c, int opt, int64_t value) {
     case 12: c->timer_mask = uint32_t(value); return 0;  // which timers record events (bit = index of mlz_timer_name)
     case 10: c->host_group_enc = size_t(value > 0 ? value : 1) << 20; return 0;  // tuning: MiB per group of a host-pointer encode batch
     case 11: c->host_group_dec = size_t(value > 0 ? value : 1) << 20; return 0;  // ... of a decode batch
-    case 15: c->index_passes = int(value); return 0;  // decode: 1 = the index pass as three kernels (dec_index_a / _b / _c: cross-checks), 0 = dec_index_kernel (default)
+    case 15: c->index_passes = int(value); return 0;  // decode: 1 = the index pass as the three kernels of rounds 2-3 (dec_index_a / _b / _c: cross-checks), 0 = dec_index1 / dec_index2 / dec_viol (default)
     case 16: c->debug_stop = int(value); return 0;  // debug: decode_batch_device returns after the index pass (out_len is not written)
+    case MLZ_OPT_DEVICE_GROUP: c->device_group = size_t(value > 0 ? value : 1) << 20; return 0;  // MiB of uncompressed data per internal group of a device batch
     case 14: c->l2_free = int(value); return 0;  // LevelBalanced: 1 = no tile levels (ratio of the reference's L2 and better; blocks decode as general blocks)
     case 13: c->gen_force_packed = int(value); return 0;  // tests: general blocks settle through the byte-packed pool (fallback path of dec_general_kernel)
     case 9: c->gen_spin_limit = value > 0 ? uint32_t(value) : 1u; return 0;  // grid-barrier patience of the general-block pass, in polls (tests)
@@ -910,14 +964,16 @@ int mlz_set_option(mlz_ctx* c, int opt, int64_t value) {
     }
     case MLZ_TIMER_ENABLE:
         if (value < 0 || value > 2) return -MLZ_ERR_ARG;
-        if (value == 2) {
+        if (value != 0) {
             for (int i = 0; i < T_COUNT; i++)
                 for (int k = 0; k < mlz_ctx::kTimerRing; k++)
                     for (int e = 0; e < 2; e++)
                         if (!c->evr[i][k][e]) HIPCHK(c, hipEventCreate(&c->evr[i][k][e]));
         }
         c->timing = int(value);
-        for (int i = 0; i < T_COUNT; i++) { c->ev_used[i] = false; c->ev_cnt[i] = c->ev_res[i] = 0; c->acc_ms[i] = 0; }
+        for (int i = 0; i < T_COUNT; i++) {   // (events recorded under the old setting are dropped unread)
+            c->ev_cnt[i] = c->ev_res[i] = 0; c->ev_calls[i] = 0; c->ev_last_call[i] = ~uint64_t(0); c->acc_ms[i] = 0;
+        }
         return 0;
     default: return -MLZ_ERR_ARG;
     }
@@ -940,6 +996,7 @@ int64_t mlz_get_counter(mlz_ctx* c, int which) {
         for (const DevBuf* b : {&c->d_dec, &c->d_idx}) d += b->cap;
         return int64_t(which == 3 ? e : d);
     }
+    if (which == 5) { std::lock_guard<std::mutex> lk(c->mu); return int64_t(c->gen_fallbacks); }
     std::lock_guard<std::mutex> lk(c->q_mu);
     return which == 0 ? int64_t(c->q_batches) : which == 1 ? int64_t(c->q_requests) : -MLZ_ERR_ARG;
 }
@@ -950,16 +1007,8 @@ int mlz_get_timers(mlz_ctx* c, float* ms, int cap) {
     int n = std::min<int>(cap, T_COUNT);
     for (int i = 0; i < n; i++) {
         ms[i] = -1.f;
-        if (c->timing == 2) {
-            while (c->ev_res[i] < c->ev_cnt[i]) c->resolve_one(i);
-            if (c->ev_res[i]) ms[i] = float(c->acc_ms[i] / double(c->ev_res[i]));
-            continue;
-        }
-        if (c->ev_used[i]) {
-            if (hipEventSynchronize(c->ev[i][1]) != hipSuccess) continue;
-            float t = 0;
-            if (hipEventElapsedTime(&t, c->ev[i][0], c->ev[i][1]) == hipSuccess) ms[i] = t;
-        }
+        while (c->ev_res[i] < c->ev_cnt[i]) c->resolve_one(i);
+        if (c->ev_calls[i]) ms[i] = float(c->acc_ms[i] / double(c->ev_calls[i]));
     }
     return n;
 }

@@ -188,9 +188,11 @@ def _host_staged(t):
 
 def gather_chunk_sizes(sizes, n_blocks, rank, world, device):
     """all_gather of the per-block chunk sizes of every rank's range -> list of n_blocks ints in stream order."""
-    if world == 1 and not (dist.is_available() and dist.is_initialized()):
+    # world == 1 is a LOCAL call unless the process group has exactly one rank too: a rank that encodes a stream of its own inside a
+    # larger job (bench.py's config-3 leg on rank 0) must not enter a collective the other ranks never join.  (A one-rank process group
+    # still goes through the collective: MINLZ_BENCH_FORCE_DIST runs RCCL's all_gather that way on a 1-GPU box.)
+    if world == 1 and not (dist.is_available() and dist.is_initialized() and dist.get_world_size() == 1):
         return list(sizes)
-    # (a one-rank process group still goes through the collective: MINLZ_BENCH_FORCE_DIST runs RCCL's all_gather that way on a 1-GPU box)
     cdev = "cpu" if dist.get_backend() == "gloo" else device
     per = (n_blocks + world - 1) // world
     t = torch.zeros(max(per, 1), dtype=torch.int64, device=cdev)

@@ -125,6 +125,11 @@ size_t model2_block(const uint8_t* src, size_t n, const Params* P, uint8_t* out,
     const int x_lbytes = getenv("MODEL_LONGBYTES") ? atoi(getenv("MODEL_LONGBYTES")) : 8;
     // MODEL_MINOFF="a,b,c": tiles of level 0 / 1 / 2 take no near match closer than a / b / c bytes (the decoder's ordered copies of a round of 64
     // tokens then depend on each other less often: fewer passes on the latency-bound low levels)
+    // MODEL_PM: the windows of an iteration are PHASE classes — window w holds the positions cur + 4 l + w (round 5: lane l owns one aligned dword group,
+    // so the four windows share the lane's raw dwords and a position's phase p & 3 is a compile-time constant); 1: look-ups and inserts window by window,
+    // 2: all look-ups of the iteration before all its inserts.  MODEL_PMCAP: the per-lane compare covers 8 raw dwords = 32 - (p & 3) bytes.
+    const int x_pm = getenv("MODEL_PM") ? atoi(getenv("MODEL_PM")) : 0;
+    const int x_pmcap = getenv("MODEL_PMCAP") ? atoi(getenv("MODEL_PMCAP")) : 0;
     const int x_l0pieces = getenv("MODEL_L0PIECES") ? atoi(getenv("MODEL_L0PIECES")) : 0;   // 1: the four 8 KiB pieces of a level-0 tile do not see each other (no seeding, no source before the piece)
     uint32_t x_minoff[4] = {0, 0, 0, 0};
     if (getenv("MODEL_MINOFF")) sscanf(getenv("MODEL_MINOFF"), "%u,%u,%u", &x_minoff[0], &x_minoff[1], &x_minoff[2]);
@@ -181,25 +186,38 @@ size_t model2_block(const uint8_t* src, size_t n, const Params* P, uint8_t* out,
                 uint32_t best[256], boff[256];
                 bool valid[256];
                 const int NP = W * NW;
+                uint32_t eA[4][64], hhA[4][64], tgA[4][64];
+                auto PI = [&](int ww, int ll) -> int { return x_pm ? 4 * ll + ww : ww * W + ll; };
+                if (x_pm == 2) {   // all look-ups of the iteration, then all its inserts (in position order: the highest position wins a bucket)
+                    for (int w = 0; w < NW; w++) for (int l = 0; l < W; l++) {
+                        const uint32_t p = cur + PI(w, l);
+                        hhA[w][l] = nidx(ld64z(s, p, tl), tgA[w][l]);
+                        eA[w][l] = table[hhA[w][l]];
+                    }
+                    for (int i = 0; i < W * NW; i++) { const int w = i & 3, l = i >> 2; if (cur + i + 4 <= pe) table[hhA[w][l]] = uint16_t((cur + i) | tgA[w][l]); }
+                }
                 for (int w = 0; w < NW; w++) {
-                    uint32_t e[64], hh[64], tg[64], e2[64], el[64], hl[64];
+                    uint32_t *e = eA[w], *hh = hhA[w], *tg = tgA[w]; uint32_t e2[64], el[64], hl[64];
                     for (int l = 0; l < W; l++) {
-                        const uint32_t p = cur + w * W + l;
-                        valid[w * W + l] = p + 4 <= pe;
+                        const uint32_t p = cur + PI(w, l);
+                        valid[PI(w, l)] = p + 4 <= pe;
+                        if (x_pm == 2) continue;
                         const uint32_t bidx = nidx(ld64z(s, p, tl), tg[l]);
                         hh[l] = x_ways == 2 ? bidx >> 1 : bidx;
                         e[l] = table[hh[l]];
                         e2[l] = x_ways == 2 ? table2[hh[l]] : 0;
                         hl[l] = x_long ? lhash(ld64z(s, p, tl)) : 0; el[l] = x_long ? ltable[hl[l]] : 0;
                     }
-                    for (int l = 0; l < W; l++) if (valid[w * W + l]) {
+                    if (x_pm != 2)
+                    for (int l = 0; l < W; l++) if (valid[PI(w, l)]) {
                         if (x_ways == 2) table2[hh[l]] = table[hh[l]];
-                        table[hh[l]] = uint16_t((cur + w * W + l) | tg[l]);
-                        if (x_long) ltable[hl[l]] = uint16_t(cur + w * W + l);
+                        table[hh[l]] = uint16_t((cur + PI(w, l)) | tg[l]);
+                        if (x_long) ltable[hl[l]] = uint16_t(cur + PI(w, l));
                     }
                     uint32_t hitoff[64];
+                    bool w_far16 = false, w_far12 = false, w_near8 = false; if (stats) stats[13]++;
                     for (int l = 0; l < W; l++) {
-                        const int i = w * W + l;
+                        const int i = PI(w, l);
                         const uint32_t p = cur + i;
                         best[i] = 0; boff[i] = 0; hitoff[l] = 0;
                         if (!valid[i]) continue;
@@ -207,7 +225,8 @@ size_t model2_block(const uint8_t* src, size_t n, const Params* P, uint8_t* out,
                         if (stats) stats[4]++;
                         const uint64_t v = ld64z(s, p, tl);
                         const uint32_t maxl = pe - p;
-                        const uint32_t lim = maxl < uint32_t(P->lane_cap) ? maxl : uint32_t(P->lane_cap);
+                        const uint32_t cap_p = uint32_t(P->lane_cap) - (x_pmcap ? (p & 3u) : 0u);
+                        const uint32_t lim = maxl < cap_p ? maxl : cap_p;
                         const uint32_t cand = e[l] & 0x7fffu;
                         const bool near_ok = cand < p && (e[l] & 0x8000u) == tg[l] && p - cand >= x_minoff[mylv];
                         const bool rep_ok = P->use_rep && rep != 0 && rep <= p;
@@ -253,6 +272,8 @@ size_t model2_block(const uint8_t* src, size_t n, const Params* P, uint8_t* out,
                                         const uint32_t lm = left < lim ? left : lim;
                                         uint32_t k = 8;
                                         while (k < lm && s[p + k] == src[fq + k]) k++;
+                                        if (k >= 16) w_far16 = true;
+                                        if (k >= 12) w_far12 = true;
                                         if (k >= uint32_t(P->min_far) && k > b + 2) { b = k; bo = off; }
                                     }
                                 }
@@ -262,6 +283,7 @@ size_t model2_block(const uint8_t* src, size_t n, const Params* P, uint8_t* out,
                         if (b < 4) b = 0;
                         best[i] = b; boff[i] = bo;
                     }
+                    if (stats) { stats[14] += w_far16; stats[15] += w_far12; }
                 }
                 // lazy
                 bool take[256];
@@ -282,7 +304,7 @@ size_t model2_block(const uint8_t* src, size_t n, const Params* P, uint8_t* out,
                     if (p < pos || !take[i]) continue;
                     uint32_t L = best[i];
                     const uint32_t off = boff[i];
-                    if (L >= uint32_t(P->lane_cap)) {  // cooperative extension
+                    if (L >= uint32_t(P->lane_cap) - (x_pmcap ? 3u : 0u)) {  // cooperative extension
                         uint32_t end = pe;
                         if (off > p) {
                             const uint32_t q = uint32_t(base) + p - off;
@@ -293,6 +315,7 @@ size_t model2_block(const uint8_t* src, size_t n, const Params* P, uint8_t* out,
                             while (p + L < end && s[p + L] == s[p - off + L]) L++;
                         }
                     }
+                    if (stats && off > p) { stats[5]++; if (L >= 13) stats[6]++; if (L >= 29) stats[7]++; }
                     recs.push_back({p, L, off});
                     pos = p + L; rep = off; any = true;
                 }

@@ -313,8 +313,11 @@ def plan_decode(blocks, rank, world):
     """blocks: S.walk_chunks(...) entries in stream order -> (b0, b1, span_lo, span_hi, u_lo, u_hi): this rank's block range,
     the byte span of the stream that holds its chunks, and the range of the decoded stream it produces."""
     b0, b1 = range_of(rank, world, len(blocks))
-    if b0 == b1:
-        return b0, b1, 0, 0, 0, 0
+    if b0 == b1:   # an empty range (more ranks than blocks) sits where its predecessors end: the ranks' ranges stay in order and cover the stream
+        if b0 == 0:
+            return b0, b1, 0, 0, 0, 0
+        pv = blocks[b0 - 1]
+        return b0, b1, pv.payload_off + pv.payload_len, pv.payload_off + pv.payload_len, pv.u_off + pv.n, pv.u_off + pv.n
     lo = blocks[b0].chunk_off
     hi = blocks[b1 - 1].payload_off + blocks[b1 - 1].payload_len
     return b0, b1, lo, hi, blocks[b0].u_off, blocks[b1 - 1].u_off + blocks[b1 - 1].n

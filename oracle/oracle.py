@@ -166,7 +166,7 @@ def stream_encode(src, level=1, block_size=8 << 20, add_index=False):
     L.mlzo_index_bound.argtypes = [C.c_size_t]; L.mlzo_index_bound.restype = C.c_size_t
     L.mlzo_stream_encode_ex.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int, C.c_size_t, C.c_int]
     L.mlzo_stream_encode_ex.restype = C.c_long
-    cap_ = L.mlzo_stream_bound(n, block_size) + (L.mlzo_index_bound((n + block_size - 1) // block_size) if add_index else 0)
+    cap_ = L.mlzo_stream_bound(n, block_size) + (L.mlzo_index_bound((n + block_size - 1) // block_size + 2) if add_index else 0)   # (+ the header's entry: the index holds blocks + 1 offsets)
     out = np.empty(cap_, dtype=np.uint8)
     r = L.mlzo_stream_encode_ex(out.ctypes.data, cap_, p, n, level, block_size, 1 if add_index else 0)
     if r < 0:

@@ -96,6 +96,87 @@ def test_sharded_stream_two_ranks():
     assert got[1] and all(got[1]), got[1]
 
 
+def _worker_many(rank, world, port, q):
+    """More ranks than blocks (empty ranks), ranges that do not divide, a failing block on a non-root rank — the shapes an 8-GPU node
+    meets (shard.range_of; writer.go:219-272 and reader.go:575-992 hand blocks to however many workers there are)."""
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import oracle as O
+        from minlz_amd import api, shard, stream, synth
+        from tests.oracle_codec import OracleTensorCodec
+        codec = OracleTensorCodec()
+        results = []
+        bs = 65536
+        for n_blocks, tail in ((5, 1234), (13, 65536), (1, 77), (8, 65536), (9, 1)):
+            n = (n_blocks - 1) * bs + tail
+            data = synth.text_like(n, 100 + n_blocks).tobytes()
+            assert (len(data) + bs - 1) // bs == n_blocks
+            # Writer: every rank frames its (possibly empty) range, the root assembles the stream
+            b0, b1 = shard.range_of(rank, world, n_blocks)
+            lo, hi = min(b0 * bs, n), min(b1 * bs, n)
+            src = torch.frombuffer(bytearray(data[lo:hi]), dtype=torch.uint8) if hi > lo else torch.zeros(0, dtype=torch.uint8)
+            out = shard.encode_stream_sharded_device(codec, src, n, bs, 1, rank, world)
+            if rank == 0:
+                sb = out.numpy().tobytes()
+                results.append(sb == O.stream_encode(data, 1, bs) and O.stream_decode(sb, n) == data)
+            # Reader: sharded output, gathered output, and the stream held by the root only
+            sb = O.stream_encode(data, 2, bs, add_index=True)
+            local, (lo2, hi2), total = shard.decode_stream_sharded_device(codec, sb, rank, world, "cpu")
+            ok = total == n and (lo2, hi2) == (lo, hi) and local.numpy().tobytes() == data[lo:hi]
+            whole, rng_, _ = shard.decode_stream_sharded_device(codec, sb, rank, world, "cpu", gather=True)
+            if rank == 0:
+                ok = ok and rng_ == (0, n) and whole.numpy().tobytes() == data
+            w2, r2, _ = shard.decode_stream_sharded_device(codec, sb if rank == 0 else None, rank, world, "cpu", gather=True, scatter=True)
+            ok = ok and w2.numpy().tobytes() == (data if rank == 0 else data[r2[0]:r2[1]])
+            results.append(bool(ok))
+        # the failing block belongs to a rank that is not the root (13 blocks on 8 ranks: block 7 is rank 4's): every rank raises
+        n = 12 * bs + 99
+        data = synth.text_like(n, 321).tobytes()
+        sb = bytearray(O.stream_encode(data, 1, bs))
+        blocks, _ = stream.walk_chunks(bytes(sb))
+        owner = next(r for r in range(world) if shard.range_of(r, world, len(blocks))[0] <= 7 < shard.range_of(r, world, len(blocks))[1])
+        results.append(owner not in (0,))
+        sb[blocks[7].payload_off + blocks[7].payload_len // 2] ^= 0x21
+        for kw in ({}, {"gather": True}):
+            try:
+                shard.decode_stream_sharded_device(codec, bytes(sb), rank, world, "cpu", **kw)
+                results.append(False)
+            except (api.ErrCRC, api.ErrCorrupt):
+                results.append(True)
+        q.put((rank, results))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_stream_eight_ranks_uneven_and_empty():
+    world = 8
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_many, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in range(world):
+        assert got[r] and all(got[r]), (r, got[r])
+
+
+def test_ranges_cover_every_block_once():
+    from minlz_amd import shard
+    for world in (1, 2, 3, 8):
+        for n in (0, 1, 5, 8, 13, 64):
+            cuts = [shard.range_of(r, world, n) for r in range(world)]
+            assert cuts[0][0] == 0 and cuts[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(cuts, cuts[1:]))
+            assert max(b - a for a, b in cuts) - min(b - a for a, b in cuts) <= 1
+
+
 def test_ownership_is_round_robin():
     from minlz_amd import shard
     assert shard.my_blocks(10, 1, 4) == [1, 5, 9]

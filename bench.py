@@ -121,38 +121,46 @@ def cpu_baseline(host, budget_s=20.0):
                              else "not timed: `go` is not installed on this box (probed at run time)"}
 
 
-def stream_mode(args, ctx, mz, synth, dist, dev, rank, world):
-    """BASELINE config 3: one stream (JSON-like by default use --workload json --level 2), blocks in contiguous ranges over the
-    ranks, every range encoded + framed on its GPU, runs gathered in order into rank 0's HBM.  Strong scaling: --bytes is the
-    whole stream.  Rank 0 prints one JSON line with per-rank kernel times and the time spent outside the kernels."""
+def stream_leg(ctx, mz, synth, dist, dev, rank, world, total, level, workload, steps, warmup, tile_from=None):
+    """BASELINE config 3: ONE stream (JSON-like, LevelBalanced by default), blocks in contiguous ranges over the ranks, every range
+    encoded + framed on its GPU, runs gathered in order into rank 0's HBM (Writer side, writer.go:219-272); then the stream just
+    written read back by all ranks (Reader side, reader.go:575-992).  Strong scaling: `total` is the whole stream.  Every rank
+    calls this; rank 0 gets the result dict (the other ranks None).  tile_from: generate at most that many bytes per rank and
+    repeat them on the device (blocks are independent: what a block compresses to does not depend on its neighbours)."""
     from minlz_amd import shard
-    total = args.bytes
     n_blocks = (total + BLOCK - 1) // BLOCK
     b0, b1 = shard.range_of(rank, world, n_blocks)
     lo, hi = min(b0 * BLOCK, total), min(b1 * BLOCK, total)
-    gen = {"enwik": synth.enwik_like, "text": synth.text_like, "json": synth.json_like, "random": synth.random_bytes}[args.workload]
-    host = gen(max(hi - lo, 1), seed=100 + rank)[:hi - lo]     # every rank generates only its own range
-    src = torch.from_numpy(host).to(dev)
+    gen = {"enwik": synth.enwik_like, "text": synth.text_like, "json": synth.json_like, "random": synth.random_bytes}[workload]
+    span = hi - lo
+    if tile_from and span > tile_from:
+        base = torch.from_numpy(gen(tile_from, seed=100 + rank)).to(dev)
+        src = base.repeat((span + tile_from - 1) // tile_from)[:span].contiguous()
+        del base
+    else:
+        src = torch.from_numpy(gen(max(span, 1), seed=100 + rank)[:span]).to(dev)     # every rank generates only its own range
     codec = shard.HipTensorCodec(ctx)
 
     def step():
-        return shard.encode_stream_sharded_device(codec, src, total, BLOCK, args.level, rank, world)
+        return shard.encode_stream_sharded_device(codec, src, total, BLOCK, level, rank, world)
     out = step()
     torch.cuda.synchronize(dev)
     clen = int(out.numel()) if out is not None else 0
-    if rank == 0 and world == 1:       # whole stream on this rank: check it (the N > 1 layout is covered by tests/test_dist_gloo.py)
-        assert mz.stream_decode(out.cpu().numpy().tobytes(), ctx=ctx) == host.tobytes()
-    for _ in range(args.warmup):
+    if rank == 0 and world == 1 and total <= (1 << 30):       # whole stream on this rank: check it (the N > 1 layout is covered by tests/test_dist_gloo.py)
+        assert mz.stream_decode(out.cpu().numpy().tobytes(), ctx=ctx) == src.cpu().numpy().tobytes()
+    for _ in range(warmup):
         step()
     torch.cuda.synchronize(dev)
+    ctx.set_option(12, 0xffffffff)
     ctx.set_option(mz.OPT_TIMING, 2)
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         step()
     torch.cuda.synchronize(dev)
+    t_local = time.perf_counter() - t0          # this rank's encode + frame + its share of the gather (before the barrier)
     if dist is not None:
         dist.barrier()
     elapsed = time.perf_counter() - t0
@@ -163,23 +171,37 @@ def stream_mode(args, ctx, mz, synth, dist, dev, rank, world):
     # Every rank holds the .mz stream in host memory (a file all ranks can read): chunk walk, upload of ITS span over its own
     # PCIe link, device decode + CRC check, output left sharded in HBM (shard.decode_stream_sharded_device).  PCIe-inclusive
     # by construction (the Reader's input is host bytes), so this is reported beside the encode rate, not as `value`.
-    box = [out.cpu().numpy().tobytes() if rank == 0 else None]
-    if dist is not None:
-        dist.broadcast_object_list(box, src=0)
-    sbytes = torch.empty(len(box[0]), dtype=torch.uint8, pin_memory=True)
-    sbytes.numpy()[:] = np.frombuffer(box[0], dtype=np.uint8)
+    if dist is not None and dist.get_backend() == "nccl":
+        # the stream travels as a device tensor (a pickled 1+ GB object through broadcast_object_list would dominate the leg's set-up)
+        nb = torch.tensor([clen], dtype=torch.int64, device=dev)
+        dist.broadcast(nb, src=0)
+        dstream = out if rank == 0 else torch.empty(int(nb.item()), dtype=torch.uint8, device=dev)
+        dist.broadcast(dstream, src=0)
+        sbytes = torch.empty(int(nb.item()), dtype=torch.uint8, pin_memory=True)
+        sbytes.copy_(dstream)
+        torch.cuda.synchronize(dev)
+        del dstream
+    else:
+        box = [out.cpu().numpy().tobytes() if rank == 0 else None]
+        if dist is not None:
+            dist.broadcast_object_list(box, src=0)
+        sbytes = torch.empty(len(box[0]), dtype=torch.uint8, pin_memory=True)
+        sbytes.numpy()[:] = np.frombuffer(box[0], dtype=np.uint8)
+        del box
+    del out
 
     def dstep():
         return shard.decode_stream_sharded_device(codec, sbytes, rank, world, dev)
     local, (ulo, uhi), dtotal = dstep()
     torch.cuda.synchronize(dev)
     assert dtotal == total and (ulo, uhi) == (lo, hi) and torch.equal(local, src), "sharded stream decode mismatch"
+    del local
     ctx.set_option(mz.OPT_TIMING, 2)
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         dstep()
     torch.cuda.synchronize(dev)
     if dist is not None:
@@ -188,33 +210,48 @@ def stream_mode(args, ctx, mz, synth, dist, dev, rank, world):
     dkern = dict(ctx.timers())
     ctx.set_option(mz.OPT_TIMING, 0)
     dk_ms = sum(v for k, v in dkern.items() if k.startswith("dec_") or k == "crc")
-    per_rank, dper_rank = [k_ms], [dk_ms]
+    per_rank, dper_rank, local_ms = [round(k_ms, 4)], [round(dk_ms, 4)], [round(t_local / steps * 1e3, 4)]
     if dist is not None:
-        tt = torch.tensor([elapsed, k_ms, d_elapsed, dk_ms], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else dev)
+        tt = torch.tensor([elapsed, k_ms, d_elapsed, dk_ms, t_local], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else dev)
         allt = [torch.zeros_like(tt) for _ in range(world)]
         dist.all_gather(allt, tt)
         elapsed = max(float(t[0]) for t in allt)
         per_rank = [round(float(t[1]), 4) for t in allt]
         d_elapsed = max(float(t[2]) for t in allt)
         dper_rank = [round(float(t[3]), 4) for t in allt]
+        local_ms = [round(float(t[4]) / steps * 1e3, 4) for t in allt]
+    if rank != 0:
+        return None
+    ms = elapsed / steps * 1e3
+    dms = d_elapsed / steps * 1e3
+    return {"workload": "%s stream of %d B in 8 MiB blocks (%d blocks), level %d, contiguous block ranges per rank, framed chunks (CRC32C on the device) "
+                        "gathered in order into rank 0's HBM" % (workload, total, n_blocks, level),
+            "scaling": "strong", "writer_MBps": round(total / 1e6 / (elapsed / steps), 1), "ms_per_step": round(ms, 4), "steps": steps,
+            "stream_bytes": clen, "ratio": round(clen / max(total, 1), 4), "kernel_ms_per_rank": per_rank,
+            # what a rank spends per step outside its kernels: the size all_gather, framing, and the payload gather into rank 0
+            "rank_ms_before_barrier": local_ms,
+            "gather_and_framing_ms": round(ms - max(per_rank), 4),
+            "reader": {"what": "the same stream from host memory on every rank: chunk walk, H2D of the rank's span, device decode + CRC check, output left sharded",
+                       "decode_MBps": round(total / 1e6 / (d_elapsed / steps), 1), "ms_per_step": round(dms, 4),
+                       "kernel_ms_per_rank": dper_rank, "outside_kernels_ms": round(dms - max(dper_rank), 4)},
+            "ranks": dist.get_world_size() if dist is not None else 1,
+            "backend": ("rccl (torch nccl)" if dist.get_backend() == "nccl" else dist.get_backend()) if dist is not None else "none (single process)"}
+
+
+def stream_mode(args, ctx, mz, synth, dist, dev, rank, world):
+    """`--mode stream`: the config-3 leg as the whole line (strong scaling: --bytes is the whole stream)."""
+    r = stream_leg(ctx, mz, synth, dist, dev, rank, world, args.bytes, args.level, args.workload, args.steps, args.warmup)
     if rank == 0:
-        ms = elapsed / args.steps * 1e3
-        dms = d_elapsed / args.steps * 1e3
-        print(json.dumps({"metric": "MB/s stream encode, 8MB blocks, one stream over N GPUs", "value": round(total / 1e6 / (elapsed / args.steps), 1), "unit": "MB/s",
-                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 4), "higher_is_better": True,
-                          "scaling": "strong", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-                          "config": {"workload": "%s stream of %d B in 8 MiB blocks, level %d, contiguous block ranges per rank, framed chunks (CRC32C on the device) "
-                                                 "gathered in order into rank 0's HBM" % (args.workload, total, args.level),
-                                     "stream_bytes": clen, "ratio": round(clen / max(total, 1), 4), "kernel_ms_per_rank": per_rank,
-                                     "outside_kernels_ms": round(ms - max(per_rank), 4),
-                                     "reader": {"what": "the same stream from host memory on every rank: chunk walk, H2D of the rank's span, device decode + CRC check, output left sharded",
-                                                "decode_MBps": round(total / 1e6 / (d_elapsed / args.steps), 1), "ms_per_step": round(dms, 4),
-                                                "kernel_ms_per_rank": dper_rank, "outside_kernels_ms": round(dms - max(dper_rank), 4)},
-                                     "ranks": dist.get_world_size() if dist is not None else 1,
-                                     "backend": ("rccl (torch nccl)" if dist.get_backend() == "nccl" else dist.get_backend()) if dist is not None else "none (single process)",
-                                     "device": ctx.device_name(),
-                                     **({"TEST_MODE": "MINLZ_BENCH_ONE_GPU: all ranks on one GPU over gloo — exercises the N > 1 code path, not a scaling measurement"}
-                                        if dist is not None and dist.get_backend() == "gloo" else {})}}), flush=True)
+        cfg = dict(r)
+        value, ms = cfg.pop("writer_MBps"), cfg.pop("ms_per_step")
+        cfg.pop("scaling"); cfg.pop("steps")
+        cfg["outside_kernels_ms"] = cfg["gather_and_framing_ms"]
+        cfg["device"] = ctx.device_name()
+        if dist is not None and dist.get_backend() == "gloo":
+            cfg["TEST_MODE"] = "MINLZ_BENCH_ONE_GPU: all ranks on one GPU over gloo — exercises the N > 1 code path, not a scaling measurement"
+        print(json.dumps({"metric": "MB/s stream encode, 8MB blocks, one stream over N GPUs", "value": value, "unit": "MB/s",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
+                          "scaling": "strong", "vs_baseline": None, "dtype": "u8", "data": "synthetic", "config": cfg}), flush=True)
     if dist is not None:
         dist.destroy_process_group()
 
@@ -234,6 +271,8 @@ def main():
                     help="blocks (default, the BASELINE metric): every rank encodes + decodes its own blocks, the compressed payload is gathered to rank 0; "
                          "stream (BASELINE config 3): ONE stream of --bytes total cut into contiguous block ranges over the ranks, framed and gathered "
                          "into rank 0's HBM (minlz_amd/shard.py), strong scaling")
+    ap.add_argument("--strong-bytes", type=int, default=4 << 30,
+                    help="N > 1, blocks mode: size of the ONE stream of the config-3 strong-scaling leg reported as config.config3_strong (0 = skip)")
     ap.add_argument("--file", default=os.environ.get("MINLZ_BENCH_FILE"), help="real input (e.g. enwik8); every rank reads its own --bytes slice, wrapping around")
     args = ap.parse_args()
 
@@ -474,6 +513,17 @@ def main():
     else:
         C_all = C_total
 
+    # ---- N > 1: BASELINE config 3 as a STRONG-scaling leg in the same line (the headline above is weak scaling: every rank its own
+    # stream): one JSON stream of --strong-bytes (default 4 GiB), LevelBalanced, written and read by all ranks (stream_leg) ----
+    strong = None
+    if dist is not None and args.strong_bytes > 0 and args.level == 1 and not args.file:
+        del main_leg.enc, main_leg.dec
+        torch.cuda.empty_cache()
+        try:
+            strong = stream_leg(ctx, mz, synth, dist, dev, rank, world, args.strong_bytes, 2, "json", 3, 1, tile_from=100_000_000)
+        except Exception as ex:      # the headline stays valid without it; every rank fails alike (same sizes, same calls) or the barrier would hang
+            strong = {"failed": "%s: %s" % (type(ex).__name__, str(ex)[:300])}
+
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
@@ -510,8 +560,16 @@ def main():
                     "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
                     "algorithmic_bytes_per_launch": alg, "avg_launch_ms": round(kavg[dom], 4),
                     "step_traffic": step_traffic, "step_algorithmic_bytes": 2 * alg,
-                    "traffic_source": ("profiles/pmc_traffic.json: a committed rocprofv3 --pmc run of this workload (%s), not measured in this run"
-                                       % tj.get("commit", "commit not recorded")) if traffic is not None else None}
+                    "traffic_source": ("profiles/pmc_traffic.json: a committed rocprofv3 --pmc run of this workload (%s), not measured in this run.  Caveats: the x2 "
+                                       "correction of the guide is calibrated for 16 B/lane streaming reads and is applied to every fetch; at 100 MB the step's working "
+                                       "set sits in the 256 MiB Infinity Cache, so these are fabric-side bytes (L2 misses), an upper bound on HBM bytes%s"
+                                       % (tj.get("commit", "commit not recorded"),
+                                          ("; the same passes on a 1 GiB stream (beyond the cache): step traffic %.2f x algorithmic" % tj["large"]["step_traffic_over_algorithmic"])
+                                          if isinstance(tj.get("large"), dict) and "step_traffic_over_algorithmic" in tj["large"] else "")) if traffic is not None else None}
+        # the two directions as wholes (all kernels of a direction against the same N + C), so that the line names more than its dominant kernel
+        roofline["by_direction"] = {
+            d: {"ms": round(t, 4), "achieved": round(alg / 1e9 / (t / 1e3), 2), "frac": round(alg / 1e9 / (t / 1e3) / HBM_PEAK_GBS, 5)}
+            for d, t in (("enc", enc_ms), ("dec", dec_ms)) if t}
 
     extras = {}
     if world == 1 and not args.no_extras:
@@ -538,6 +596,18 @@ def main():
         torch.cuda.synchronize(dev)
         extras["decode_foreign_MBps"] = round(S / 1e6 / ((time.perf_counter() - t0) / 10), 1)
         extras["decode_foreign_ratio"] = round(sum(lens) / S, 4)
+        # the kernel furthest below its roofline: the general-block pass on few large blocks (its own timer, a pass outside the clock above)
+        ctx.set_option(12, 0xffffffff); ctx.set_option(mz.OPT_TIMING, 2)
+        for _ in range(5):
+            main_leg.run_decode()
+        torch.cuda.synchronize(dev)
+        fk = dict(ctx.timers()); ctx.set_option(mz.OPT_TIMING, 0)
+        if roofline is not None and fk.get("dec_general"):
+            falg = S + sum(lens)
+            roofline["foreign"] = {"kernel": "dec_general", "what": "%d reference-made 8 MiB blocks (the oracle's L1 output of the bench stream), decode only" % nblk,
+                                   "avg_launch_ms": round(fk["dec_general"], 4), "algorithmic_bytes_per_launch": falg,
+                                   "achieved": round(falg / 1e9 / (fk["dec_general"] / 1e3), 2), "frac": round(falg / 1e9 / (fk["dec_general"] / 1e3) / HBM_PEAK_GBS, 5),
+                                   "decode_kernel_ms": {k: round(v, 4) for k, v in fk.items() if k.startswith("dec_")}}
         # ... and cut into blocks of the reference Writer's default size (2 MiB, minlz.go:106): what a .mz file made with
         # default options holds
         from minlz_amd._lib import BlockDesc
@@ -648,7 +718,7 @@ def main():
                 del base
                 leg4 = Leg(big, level=2)
                 r4 = leg4.summary(2, warmup=1)
-                r4["general_blocks"] = ctx.general_blocks()
+                r4["general_blocks_in_last_group"] = ctx.general_blocks()   # (a device batch runs in internal groups of 512 MiB = 64 of these blocks)
                 ws_e, ws_d = ctx.workspace_bytes()
                 r4["workspace_bytes"] = {"encode": ws_e, "decode": ws_d}
                 del leg4
@@ -748,6 +818,8 @@ def main():
     cfg.update(extras)
     if gather_info:
         cfg["gather"] = gather_info
+    if strong is not None:
+        cfg["config3_strong"] = strong
     out = {
         "metric": "MB/s encode+decode, 8MB blocks %s" % {1: "L1", 2: "L2 (LevelBalanced)", -1: "L0 (LevelSuperFast)", 0: "uncompressed"}.get(args.level, "level %d" % args.level),
         "value": round(value, 1),

@@ -179,13 +179,18 @@ def test_bench_one_rank_over_rccl(mode):
     env["MINLZ_BENCH_FORCE_DIST"] = "1"
     env["MASTER_PORT"] = str(_free_port())
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--no-cpu", "--no-extras", "--bytes", "33554432"]
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--no-cpu", "--no-extras", "--bytes", "33554432",
+           "--strong-bytes", "50331648"]
     if mode == "stream":
         cmd += ["--mode", "stream", "--workload", "json", "--level", "2"]
     r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert d["n_gpus"] == 1 and d["value"] > 0 and d["config"]["ranks"] == 1 and d["config"]["backend"].startswith("rccl") and "TEST_MODE" not in d["config"]
+    if mode == "blocks":   # the config-3 strong-scaling leg rides in the same line whenever a process group exists (device broadcast of the stream over RCCL)
+        cs = d["config"]["config3_strong"]
+        assert "failed" not in cs, cs
+        assert cs["scaling"] == "strong" and cs["writer_MBps"] > 0 and cs["reader"]["decode_MBps"] > 0 and cs["backend"].startswith("rccl")
 
 
 @pytest.mark.parametrize("mode", ["blocks", "stream"])
@@ -199,7 +204,8 @@ def test_bench_two_ranks_on_one_gpu(mode):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
     env["MINLZ_BENCH_ONE_GPU"] = "1"
-    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu", "--no-extras", "--bytes", "33554432"]
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu", "--no-extras", "--bytes", "33554432",
+           "--strong-bytes", str(5 * (8 << 20) + 12345)]          # five blocks and a bit over two ranks: uneven ranges, a ragged last block
     if mode == "stream":
         cmd += ["--mode", "stream", "--workload", "json", "--level", "2"]
     r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900)
@@ -211,3 +217,6 @@ def test_bench_two_ranks_on_one_gpu(mode):
         assert len(d["config"]["kernel_ms_per_rank"]) == 2 and d["config"]["reader"]["decode_MBps"] > 0
     else:
         assert d["config"]["gather"]["payload_bytes_per_step"] > 0
+        cs = d["config"]["config3_strong"]
+        assert "failed" not in cs, cs
+        assert cs["ranks"] == 2 and len(cs["kernel_ms_per_rank"]) == 2 and len(cs["rank_ms_before_barrier"]) == 2 and cs["reader"]["decode_MBps"] > 0

@@ -19,6 +19,6 @@ st = torch.cuda.current_stream(dev).cuda_stream
 for _ in range(3): ctx.encode_batch_device(st, 1, src.data_ptr(), enc.data_ptr(), desc, el.data_ptr())
 torch.cuda.synchronize()
 ctx.set_option(mz.OPT_TIMING, 2)
-for _ in range(10): ctx.encode_batch_device(st, 1, src.data_ptr(), enc.data_ptr(), desc, el.data_ptr())
+for _ in range(int(os.environ.get('ENC_TIME_REPS', '10'))): ctx.encode_batch_device(st, 1, src.data_ptr(), enc.data_ptr(), desc, el.data_ptr())
 torch.cuda.synchronize()
 print(os.path.basename(os.environ.get("MINLZ_HIP_LIB", "product")), "ratio %.4f" % (el.sum().item() / S), {k: round(v, 4) for k, v in ctx.timers().items()})

@@ -86,6 +86,11 @@ struct Params {
     int far_bits;     // far table entries per (epoch, level set), log2 (LevelFastest 17, LevelBalanced 18)
     int far_stride;   // every far_stride-th 8-byte window is entered into the far tables (4 / 2)
     int seed_stride;  // every seed_stride-th earlier position of the tile seeds a piece's near table (2 / 1)
+    int pm;           // round-5 experiments (built as kernel variants, measured, NOT kept: DESIGN.md section 3 "Own-phase compares"; the kernels are 0).
+                      // 2: own-phase compares — a lane compares 8 raw dwords = 32 - (p & 3) bytes, and far candidates below position 4 are not used (their
+                      // bytes are loaded at q - (p & 3)).  1: in addition the four windows of an iteration are the four PHASES — window k = positions
+                      // cur + 4 l + k —, all look-ups of the iteration come before its inserts (inserts window by window, lanes in order).
+    int near_unit;    // graded near tables: entries per 8 KiB of indexed positions (0: 2^near_bits / sub; the kernels' 12-bit class in phase-major form: 992)
 };
 
 struct Rec { uint32_t mp, len, off; };
@@ -128,8 +133,8 @@ size_t model2_block(const uint8_t* src, size_t n, const Params* P, uint8_t* out,
     // MODEL_PM: the windows of an iteration are PHASE classes — window w holds the positions cur + 4 l + w (round 5: lane l owns one aligned dword group,
     // so the four windows share the lane's raw dwords and a position's phase p & 3 is a compile-time constant); 1: look-ups and inserts window by window,
     // 2: all look-ups of the iteration before all its inserts.  MODEL_PMCAP: the per-lane compare covers 8 raw dwords = 32 - (p & 3) bytes.
-    const int x_pm = getenv("MODEL_PM") ? atoi(getenv("MODEL_PM")) : 0;
-    const int x_pmcap = getenv("MODEL_PMCAP") ? atoi(getenv("MODEL_PMCAP")) : 0;
+    const int x_pm = getenv("MODEL_PM") ? atoi(getenv("MODEL_PM")) : P->pm == 1 ? 2 : 0;
+    const int x_pmcap = getenv("MODEL_PMCAP") ? atoi(getenv("MODEL_PMCAP")) : P->pm != 0;
     const int x_l0pieces = getenv("MODEL_L0PIECES") ? atoi(getenv("MODEL_L0PIECES")) : 0;   // 1: the four 8 KiB pieces of a level-0 tile do not see each other (no seeding, no source before the piece)
     uint32_t x_minoff[4] = {0, 0, 0, 0};
     if (getenv("MODEL_MINOFF")) sscanf(getenv("MODEL_MINOFF"), "%u,%u,%u", &x_minoff[0], &x_minoff[1], &x_minoff[2]);
@@ -152,7 +157,7 @@ size_t model2_block(const uint8_t* src, size_t n, const Params* P, uint8_t* out,
             recs.clear();
             std::fill(table.begin(), table.end(), uint16_t(0));
             std::fill(table2.begin(), table2.end(), uint16_t(0)); std::fill(ltable.begin(), ltable.end(), uint16_t(0));
-            const uint32_t tsize = P->graded ? uint32_t(((ps / piece_len) + 1) * (table.size() / size_t(P->sub))) : uint32_t(table.size());
+            const uint32_t tsize = P->graded ? uint32_t(((ps / piece_len) + 1) * (P->near_unit ? size_t(P->near_unit) : table.size() / size_t(P->sub))) : uint32_t(table.size());
             const bool mulhi = P->far_hash24 == 2;   // round-3 hashes: near bucket = mul_hi(hash32, table size), far hash from two 32-bit multiplies
             auto tix = [&](uint32_t h) -> uint32_t { return uint32_t((uint64_t(h) * tsize) >> P->near_bits); };
             auto nidx = [&](uint64_t v8, uint32_t& tag) -> uint32_t {
@@ -188,13 +193,13 @@ size_t model2_block(const uint8_t* src, size_t n, const Params* P, uint8_t* out,
                 const int NP = W * NW;
                 uint32_t eA[4][64], hhA[4][64], tgA[4][64];
                 auto PI = [&](int ww, int ll) -> int { return x_pm ? 4 * ll + ww : ww * W + ll; };
-                if (x_pm == 2) {   // all look-ups of the iteration, then all its inserts (in position order: the highest position wins a bucket)
+                if (x_pm == 2) {   // all look-ups of the iteration, then all its inserts (window by window = phase by phase, lanes in order: what four LDS store instructions do)
                     for (int w = 0; w < NW; w++) for (int l = 0; l < W; l++) {
                         const uint32_t p = cur + PI(w, l);
                         hhA[w][l] = nidx(ld64z(s, p, tl), tgA[w][l]);
                         eA[w][l] = table[hhA[w][l]];
                     }
-                    for (int i = 0; i < W * NW; i++) { const int w = i & 3, l = i >> 2; if (cur + i + 4 <= pe) table[hhA[w][l]] = uint16_t((cur + i) | tgA[w][l]); }
+                    for (int w = 0; w < NW; w++) for (int l = 0; l < W; l++) { const int i = 4 * l + w; if (cur + i + 4 <= pe) table[hhA[w][l]] = uint16_t((cur + i) | tgA[w][l]); }
                 }
                 for (int w = 0; w < NW; w++) {
                     uint32_t *e = eA[w], *hh = hhA[w], *tg = tgA[w]; uint32_t e2[64], el[64], hl[64];
@@ -264,7 +269,7 @@ size_t model2_block(const uint8_t* src, size_t n, const Params* P, uint8_t* out,
                                 const uint32_t left = kTile - (fq & (kTile - 1));
                                 if (kk == 0 && fq < base) hitoff[l] = off;
                                 if (x_heads && kk == 0 && fq < base && (l & 15) >= x_heads && hitoff[l - x_heads] == off) continue;
-                                if (fq < base && off <= kMaxCopy3Offset && left >= 8) {
+                                if (fq < base && off <= kMaxCopy3Offset && left >= 8 && !(x_pmcap && fq < 4)) {
                                     uint64_t fv; memcpy(&fv, src + fq, 8);
                                     const bool deep = base + p + 40 <= n;  // the kernel looks at a far candidate only when 32 bytes are readable on both sides
                                     if (stats && fv == v) stats[12]++;

@@ -114,7 +114,8 @@ struct mlz_ctx {
     hipStream_t ws_stream = nullptr;
     bool ws_used = false;
     // encode workspace
-    DevBuf d_scratch, d_tile_size, d_tile_out, d_flags, d_far, d_recs, d_piece_cnt;
+    DevBuf d_scratch, d_tile_size, d_tile_out, d_flags, d_far, d_recs, d_piece_cnt, d_farbin;
+    bool farbin_attr = false;
     // decode workspace
     DevBuf d_dec, d_idx;
     int general_algo = 0;  // 0 = pointer-jumping pass for general blocks, 1 = tile chain in the exec pass
@@ -122,6 +123,7 @@ struct mlz_ctx {
     int gen_grid = 0;      // workgroups of dec_general_kernel the device holds at once
     uint32_t gen_spin_limit = 1u << 24;  // role S's patience with a tile's ready flag, in polls (~0.3 us each): ~5 s
     int n_cus = 0;
+    int far_slices_l2 = 0;     // debug option 18: 1 = LevelBalanced's far tables by far_build_kernel (slice workgroups, round 4) even without level sets
     int l2_free = 1;           // option 14 (default on): LevelBalanced without the tile-level constraint (better ratio; its blocks decode through the general path)
     uint64_t gen_fallbacks = 0;  // decode calls whose general blocks took the tile chain because the general pass's buffers could not be allocated (mlz_get_counter 5)
     int gen_force_packed = 0;  // tests: every tile of a general block takes the byte-packed pool (the fallback path)
@@ -327,7 +329,7 @@ int encode_device_group(mlz_ctx* c, hipStream_t st, int level, const uint8_t* d_
         const int fbits = any_big ? (l2new ? kL2FarBits : kFarBits) : small_far_bits(maxlen) + (l2new ? 1 : 0);
         if (far) {
             Timer t(c, T_FAR, st);
-            const size_t words = (size_t(n) * (kLevels - 1) * epochs) << fbits;
+            const size_t words = (size_t(n) * far_sets(pattern) * epochs) << fbits;
             HIPCHK(c, c->d_far.ensure(words * 4));
             if (!c->far_attr) {
                 HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(far_build_kernel<kFarBits, kFarStride>), hipFuncAttributeMaxDynamicSharedMemorySize, 4u << kFarSliceBits));
@@ -337,7 +339,23 @@ int encode_device_group(mlz_ctx* c, hipStream_t st, int level, const uint8_t* d_
                 c->far_attr = true;
             }
             if (any_big) {
-                if (l2new)
+                if (l2new && pattern == kPatternFree && !c->far_slices_l2) {
+                    // no level sets: the windows sorted by slice once (far_bin_kernel), every slice workgroup reads its eighth (far_slice_kernel)
+                    using FBn = FarBin<kL2FarBits, kL2FarStride>;
+                    const size_t units2 = size_t(tiles) * 2;
+                    HIPCHK(c, c->d_farbin.ensure(units2 * FBn::kPerUnit * 4 + units2 * FBn::kOffs * 4 + 256));
+                    uint32_t* bins = c->d_farbin.as<uint32_t>();
+                    uint32_t* binoff = bins + units2 * FBn::kPerUnit;
+                    constexpr uint32_t kSliceLds = (4u << kBinSliceBits) + 256 * 4 + 132 * 4;
+                    if (!c->farbin_attr) {
+                        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(far_bin_kernel<kL2FarBits, kL2FarStride>), hipFuncAttributeMaxDynamicSharedMemorySize, FBn::kLds));
+                        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(far_slice_kernel<kL2FarBits, kL2FarStride>), hipFuncAttributeMaxDynamicSharedMemorySize, kSliceLds));
+                        c->farbin_attr = true;
+                    }
+                    hipLaunchKernelGGL((far_bin_kernel<kL2FarBits, kL2FarStride>), dim3(uint32_t(units2)), dim3(256), FBn::kLds, st, d_src, blocks, tile_block, bins, binoff);
+                    hipLaunchKernelGGL((far_slice_kernel<kL2FarBits, kL2FarStride>), dim3(FBn::kSlices, epochs, n), dim3(1024), kSliceLds, st, blocks,
+                                       bins, binoff, c->d_far.as<uint32_t>(), epochs);
+                } else if (l2new)
                     hipLaunchKernelGGL((far_build_kernel<kL2FarBits, kL2FarStride>), dim3(far_slices(kL2FarBits), epochs, n), dim3(1024), 4u << kFarSliceBits, st, d_src,
                                        blocks, c->d_far.as<uint32_t>(), epochs, pattern, uint32_t(fbits), any_small ? 1u : 2u);
                 else
@@ -804,7 +822,7 @@ void mlz_destroy(mlz_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
-    for (DevBuf* b : {&c->d_place, &c->d_crc, &c->d_crc_tabs, &c->d_crc_tiles, &c->d_prof, &c->d_blocks_k[0], &c->d_blocks_k[1], &c->d_tile_block_k[0], &c->d_tile_block_k[1], &c->d_seg_block_k[0], &c->d_seg_block_k[1], &c->d_scratch, &c->d_tile_size, &c->d_tile_out, &c->d_flags, &c->d_far, &c->d_recs, &c->d_piece_cnt, &c->d_dec, &c->d_idx, &c->d_in, &c->d_out, &c->d_len})
+    for (DevBuf* b : {&c->d_place, &c->d_crc, &c->d_crc_tabs, &c->d_crc_tiles, &c->d_prof, &c->d_blocks_k[0], &c->d_blocks_k[1], &c->d_tile_block_k[0], &c->d_tile_block_k[1], &c->d_seg_block_k[0], &c->d_seg_block_k[1], &c->d_scratch, &c->d_tile_size, &c->d_tile_out, &c->d_flags, &c->d_far, &c->d_farbin, &c->d_recs, &c->d_piece_cnt, &c->d_dec, &c->d_idx, &c->d_in, &c->d_out, &c->d_len})
         b->release();
     for (int k = 0; k < 2; k++) if (c->pinned_k[k]) (void)hipHostFree(c->pinned_k[k]);
     if (c->pinned2) (void)hipHostFree(c->pinned2);
@@ -941,6 +959,7 @@ int mlz_set_option(mlz_ctx* c, int opt, int64_t value) {
     case 15: c->index_passes = int(value); return 0;  // decode: 1 = the index pass as the three kernels of rounds 2-3 (dec_index_a / _b / _c: cross-checks), 0 = dec_index1 / dec_index2 / dec_viol (default)
     case 16: c->debug_stop = int(value); return 0;  // debug: decode_batch_device returns after the index pass (out_len is not written)
     case MLZ_OPT_DEVICE_GROUP: c->device_group = size_t(value > 0 ? value : 1) << 20; return 0;  // MiB of uncompressed data per internal group of a device batch
+    case 18: c->far_slices_l2 = int(value); return 0;  // debug / cross-check: LevelBalanced's far tables by the slice kernel of round 4
     case 14: c->l2_free = int(value); return 0;  // LevelBalanced: 1 = no tile levels (ratio of the reference's L2 and better; blocks decode as general blocks)
     case 13: c->gen_force_packed = int(value); return 0;  // tests: general blocks settle through the byte-packed pool (fallback path of dec_general_kernel)
     case 9: c->gen_spin_limit = value > 0 ? uint32_t(value) : 1u; return 0;  // grid-barrier patience of the general-block pass, in polls (tests)
@@ -992,7 +1011,7 @@ int64_t mlz_get_counter(mlz_ctx* c, int which) {
     if (which == 3 || which == 4) {  // device workspace this context holds: 3 = encode side, 4 = decode side (grow-only buffers: the high-water mark of the calls so far)
         std::lock_guard<std::mutex> lk(c->mu);
         size_t e = 0, d = 0;
-        for (const DevBuf* b : {&c->d_scratch, &c->d_tile_size, &c->d_tile_out, &c->d_flags, &c->d_far, &c->d_recs, &c->d_piece_cnt}) e += b->cap;
+        for (const DevBuf* b : {&c->d_scratch, &c->d_tile_size, &c->d_tile_out, &c->d_flags, &c->d_far, &c->d_recs, &c->d_piece_cnt, &c->d_farbin}) e += b->cap;
         for (const DevBuf* b : {&c->d_dec, &c->d_idx}) d += b->cap;
         return int64_t(which == 3 ? e : d);
     }

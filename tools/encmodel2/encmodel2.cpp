@@ -135,6 +135,9 @@ size_t model2_block(const uint8_t* src, size_t n, const Params* P, uint8_t* out,
     // 2: all look-ups of the iteration before all its inserts.  MODEL_PMCAP: the per-lane compare covers 8 raw dwords = 32 - (p & 3) bytes.
     const int x_pm = getenv("MODEL_PM") ? atoi(getenv("MODEL_PM")) : P->pm == 1 ? 2 : 0;
     const int x_pmcap = getenv("MODEL_PMCAP") ? atoi(getenv("MODEL_PMCAP")) : P->pm != 0;
+    // MODEL_MINTILES=K (round 5, with no tile levels): a far source lies at least K tiles back (or in the own tile: near matches) — K consecutive tiles of a
+    // block then never read each other and a decoder could settle them side by side
+    const uint32_t x_mintiles = getenv("MODEL_MINTILES") ? uint32_t(atoi(getenv("MODEL_MINTILES"))) : 1;
     const int x_l0pieces = getenv("MODEL_L0PIECES") ? atoi(getenv("MODEL_L0PIECES")) : 0;   // 1: the four 8 KiB pieces of a level-0 tile do not see each other (no seeding, no source before the piece)
     uint32_t x_minoff[4] = {0, 0, 0, 0};
     if (getenv("MODEL_MINOFF")) sscanf(getenv("MODEL_MINOFF"), "%u,%u,%u", &x_minoff[0], &x_minoff[1], &x_minoff[2]);
@@ -269,7 +272,7 @@ size_t model2_block(const uint8_t* src, size_t n, const Params* P, uint8_t* out,
                                 const uint32_t left = kTile - (fq & (kTile - 1));
                                 if (kk == 0 && fq < base) hitoff[l] = off;
                                 if (x_heads && kk == 0 && fq < base && (l & 15) >= x_heads && hitoff[l - x_heads] == off) continue;
-                                if (fq < base && off <= kMaxCopy3Offset && left >= 8 && !(x_pmcap && fq < 4)) {
+                                if (fq < base && off <= kMaxCopy3Offset && left >= 8 && !(x_pmcap && fq < 4) && (uint32_t(t) - (fq >> kTileLog)) >= x_mintiles) {
                                     uint64_t fv; memcpy(&fv, src + fq, 8);
                                     const bool deep = base + p + 40 <= n;  // the kernel looks at a far candidate only when 32 bytes are readable on both sides
                                     if (stats && fv == v) stats[12]++;

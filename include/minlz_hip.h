@@ -145,6 +145,10 @@ int64_t mlz_stream_decode(mlz_ctx* ctx, uint32_t flags, const uint8_t* src, size
                                 * reference's encode_l2.go and better (0.93 - 1.05 x its restatement), and the blocks decode, like the reference's own,
                                 * through the general-block path; 0 = the four-level tile pattern of rounds 1-3 (1.08 - 1.09 x, level-scheduled decode) */
 #define MLZ_OPT_DEVICE_GROUP 17 /* MiB of uncompressed data per internal group of a device batch (default 512): bounds the workspace */
+#define MLZ_OPT_L2_GAP 19      /* LevelBalanced without tile levels: a copy from another tile reads at least this many tiles back (default 4; 1 = anywhere,
+                                * rounds 4's form).  With K >= 2 the K tiles in front of a tile never feed it, and the decoder settles K (2 or 4) tiles of a
+                                * block side by side instead of one: 0.3 - 1.0 % (K = 2) / 0.8 - 2.6 % (K = 4) of output for 2 - 3 x the decode rate of
+                                * batches of few large blocks.  The decoder measures the distance itself: any stream that keeps it decodes this way. */
 #define MLZ_OPT_INDEX_PASSES 15 /* decode, cross-checks: 1 = the index pass as the three kernels of rounds 2-3 instead of dec_index1 / dec_index2 / dec_viol (default 0) */
 /* (debug, timing experiments: option 16 = 1 makes mlz_decode_batch_device return after the index pass, without output) */
 #define MLZ_OPT_GEN_SPIN 9     /* patience of the general-block decode with a tile's ready flag, in polls (~0.3 us each; default 2^24); tests */

@@ -11,7 +11,7 @@ LevelSuperFast, LevelUncompressed, LevelFastest, LevelBalanced = -1, 0, 1, 2  # 
 MaxBlockSize = 8 << 20  # minlz.go:84
 
 OPT_DECODE_ALGO, OPT_ENCODE_FAR, OPT_TIMING = 1, 2, 100
-OPT_L2_FREE, OPT_GEN_SPIN, OPT_GEN_PACKED, OPT_INDEX_PASSES = 14, 9, 13, 15   # include/minlz_hip.h
+OPT_L2_FREE, OPT_GEN_SPIN, OPT_GEN_PACKED, OPT_INDEX_PASSES, OPT_DEVICE_GROUP, OPT_L2_GAP = 14, 9, 13, 15, 17, 19   # include/minlz_hip.h
 
 
 class MinLZError(Exception):

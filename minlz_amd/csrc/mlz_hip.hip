@@ -124,6 +124,7 @@ struct mlz_ctx {
     uint32_t gen_spin_limit = 1u << 24;  // role S's patience with a tile's ready flag, in polls (~0.3 us each): ~5 s
     int n_cus = 0;
     int far_slices_l2 = 0;     // debug option 18: 1 = LevelBalanced's far tables by far_build_kernel (slice workgroups, round 4) even without level sets
+    int l2_gap = 4;            // option 19: LevelBalanced without levels: a far source lies at least this many tiles back (1 = anywhere; 4: the decoder settles four tiles of a block side by side)
     int l2_free = 1;           // option 14 (default on): LevelBalanced without the tile-level constraint (better ratio; its blocks decode through the general path)
     uint64_t gen_fallbacks = 0;  // decode calls whose general blocks took the tile chain because the general pass's buffers could not be allocated (mlz_get_counter 5)
     int gen_force_packed = 0;  // tests: every tile of a general block takes the byte-packed pool (the fallback path)
@@ -377,6 +378,8 @@ int encode_device_group(mlz_ctx* c, hipStream_t st, int level, const uint8_t* d_
             }
         }
         const uint32_t* ftab = far ? c->d_far.as<uint32_t>() : nullptr;
+        // LevelBalanced without levels: far sources at least l2_gap tiles back (MLZ_OPT_L2_GAP)
+        const uint32_t far_gap = pattern == kPatternFree && level == MLZ_LEVEL_BALANCED ? uint32_t(c->l2_gap - 1) << kTileLog : 0u;
         {
             HIPCHK(c, c->d_recs.ensure(units * kRecPerPiece * sizeof(uint2)));
             HIPCHK(c, c->d_piece_cnt.ensure(units * sizeof(uint32_t)));
@@ -385,22 +388,22 @@ int encode_device_group(mlz_ctx* c, hipStream_t st, int level, const uint8_t* d_
                 const uint32_t grid = ((tiles + 7) / 8) * 8;  // whole rounds of the eight XCDs (see the kernel's workgroup -> tile map)
 #define MLZ_LAUNCH_M2(F, HB, CLS, ...)                                                                                                       \
     hipLaunchKernelGGL((match_tiles_kernel<F, MLZ_M2_NW, HB, ##__VA_ARGS__>), dim3(grid), dim3(256), M2Cfg<HB>::kLds, st, d_src, blocks, tile_block,        \
-                       c->d_recs.as<uint2>(), c->d_piece_cnt.as<uint32_t>(), ftab, epochs, pattern, tiles, uint32_t(CLS), uint32_t(fbits))
+                       c->d_recs.as<uint2>(), c->d_piece_cnt.as<uint32_t>(), ftab, epochs, pattern, tiles, uint32_t(CLS), uint32_t(fbits), far_gap)
                 if (level == MLZ_LEVEL_SUPERFAST) MLZ_LAUNCH_M2(false, kM2HashBitsSuperFast, 2);
                 else if (l2new && far) {
                     // the same kernel for both block classes, with far tables of the level's size or of the block's
                     if (any_big)
                         hipLaunchKernelGGL((match_tiles_kernel<true, MLZ_M2_NW, kM2HashBitsSmall, kL2FarBits, true>), dim3(grid), dim3(256), M2Cfg<kM2HashBitsSmall>::kLds,
                                            st, d_src, blocks, tile_block, c->d_recs.as<uint2>(), c->d_piece_cnt.as<uint32_t>(), ftab, epochs, pattern, tiles,
-                                           any_small ? 1u : 2u, uint32_t(fbits));
+                                           any_small ? 1u : 2u, uint32_t(fbits), far_gap);
                     if (any_small)
                         hipLaunchKernelGGL((match_tiles_kernel<true, MLZ_M2_NW, kM2HashBitsSmall, 0, true>), dim3(grid), dim3(256), M2Cfg<kM2HashBitsSmall>::kLds, st,
                                            d_src, blocks, tile_block, c->d_recs.as<uint2>(), c->d_piece_cnt.as<uint32_t>(), ftab, epochs, pattern, tiles,
-                                           any_big ? 0u : 2u, uint32_t(fbits));
+                                           any_big ? 0u : 2u, uint32_t(fbits), far_gap);
                 }
                 else if (l2new)   // blocks of one tile: no far tables, but the same near-table seeding as the level's other blocks
                     hipLaunchKernelGGL((match_tiles_kernel<false, MLZ_M2_NW, kM2HashBitsSmall, kL2FarBits, true>), dim3(grid), dim3(256), M2Cfg<kM2HashBitsSmall>::kLds, st,
-                                       d_src, blocks, tile_block, c->d_recs.as<uint2>(), c->d_piece_cnt.as<uint32_t>(), ftab, epochs, pattern, tiles, 2u, uint32_t(fbits));
+                                       d_src, blocks, tile_block, c->d_recs.as<uint2>(), c->d_piece_cnt.as<uint32_t>(), ftab, epochs, pattern, tiles, 2u, uint32_t(fbits), far_gap);
                 else {
                     // one launch per block class that occurs in the batch (usually one)
                     if (any_big) { if (far) MLZ_LAUNCH_M2(true, kM2HashBitsBig, any_small ? 1 : 2); else MLZ_LAUNCH_M2(false, kM2HashBitsBig, any_small ? 1 : 2); }
@@ -527,7 +530,6 @@ int decode_parallel(mlz_ctx* c, hipStream_t st, const uint8_t* d_src, uint8_t* d
             hipLaunchKernelGGL(dec_index1_kernel, dim3(segs), dim3(kIdxThreads), kIdxLds, st, d_src, blocks, seg_block, dec, seg_entry, rexit_tab, sstate, sstate + segs, tok16);
             hipLaunchKernelGGL(dec_index2_kernel, dim3(2 * segs), dim3(kIdx2Threads), 0, st, d_src, blocks, seg_block, dec, sstate, sstate + segs, tok16, tile_start, tok_pos,
                                round_d, round_rep, ws + o_sviol);
-            hipLaunchKernelGGL(dec_viol_kernel, dim3((segs + 255) / 256), dim3(256), 0, st, seg_block, ws + o_sviol, dec, jump ? &gen->n_general : nullptr, segs);
         }
         if (c->index_passes) {   // the three-kernel form (cross-checks)
             if (segs)
@@ -538,8 +540,11 @@ int decode_parallel(mlz_ctx* c, hipStream_t st, const uint8_t* d_src, uint8_t* d
                                    tile_start, reg_out, reg_last, reg_entry, seg_ntok, tok_pos, round_d, round_rep,
                                    jump ? &gen->n_general : nullptr);
         }
+        // (+ the per-block gather of the index pass's verdict bytes: D3 / 3)
+        const bool gather_viol = segs && !c->index_passes;
         if (tiles) hipLaunchKernelGGL(dec_schedule_kernel, dim3(1), dim3(1024), 0, st, blocks, tile_block, dec, order, tiles, uint32_t(n),
-                                      jump ? reinterpret_cast<uint32_t*>(ws + o_glist) : nullptr, reinterpret_cast<uint32_t*>(gen));
+                                      jump ? reinterpret_cast<uint32_t*>(ws + o_glist) : nullptr, reinterpret_cast<uint32_t*>(gen), seg_block,
+                                      gather_viol ? ws + o_sviol : nullptr, segs, jump ? &gen->n_general : nullptr);
     }
     if (c->debug_stop) { HIPCHK(c, hipGetLastError()); return 0; }
     {
@@ -564,7 +569,8 @@ int decode_parallel(mlz_ctx* c, hipStream_t st, const uint8_t* d_src, uint8_t* d
             }
             if (c->gen_grid == 0) { c->err = "dec_general_kernel: the device cannot hold a workgroup"; return -MLZ_ERR_HIP; }
             // role S: one workgroup per general block, at most a quarter of the device (more blocks take turns); role E: the rest
-            const uint32_t nS = std::max<uint32_t>(1u, std::min<uint32_t>(uint32_t(n), uint32_t(c->gen_grid) / 4));
+            // (a multiple of 4: blocks whose tiles do not read their nearest neighbours are settled by teams of 2 or 4 workgroups, GenCtl::team)
+            const uint32_t nS = std::max<uint32_t>(4u, std::min<uint32_t>(4u * uint32_t(n), uint32_t(c->gen_grid) / 4) & ~3u);
             const uint32_t nE = std::max<uint32_t>(1u, uint32_t(c->gen_grid) > nS ? uint32_t(c->gen_grid) - nS : 1u);
             hipLaunchKernelGGL(dec_general_kernel, dim3(nE + nS), dim3(kGenThreads), kGenLds, st, d_src, d_dst, blocks, dec, tok_pos, round_d, round_rep, tile_start,
                                reinterpret_cast<const uint32_t*>(ws + o_glist), c->d_idx.as<uint16_t>(), c->d_idx.as<uint8_t>() + (size_t(tiles) << kTileLog) * 2,
@@ -960,6 +966,7 @@ int mlz_set_option(mlz_ctx* c, int opt, int64_t value) {
     case 16: c->debug_stop = int(value); return 0;  // debug: decode_batch_device returns after the index pass (out_len is not written)
     case MLZ_OPT_DEVICE_GROUP: c->device_group = size_t(value > 0 ? value : 1) << 20; return 0;  // MiB of uncompressed data per internal group of a device batch
     case 18: c->far_slices_l2 = int(value); return 0;  // debug / cross-check: LevelBalanced's far tables by the slice kernel of round 4
+    case MLZ_OPT_L2_GAP: if (value < 1 || value > 16) return -MLZ_ERR_ARG; c->l2_gap = int(value); return 0;
     case 14: c->l2_free = int(value); return 0;  // LevelBalanced: 1 = no tile levels (ratio of the reference's L2 and better; blocks decode as general blocks)
     case 13: c->gen_force_packed = int(value); return 0;  // tests: general blocks settle through the byte-packed pool (fallback path of dec_general_kernel)
     case 9: c->gen_spin_limit = value > 0 ? uint32_t(value) : 1u; return 0;  // grid-barrier patience of the general-block pass, in polls (tests)

@@ -22,7 +22,9 @@ pytestmark = pytest.mark.gpu
 # and on 64 KiB blocks (the reference's small-block classes, encode_l1.go:285-524 / encode_l0.go:281-522):
 #   C_gpu(1) <= RATIO_TOL_64K * C_oracle(L1)
 RATIO_TOL = {"enwik": 1.02, "text": 1.04, "json": 1.04, "json_text": 1.08, "twain": 1.08}
-RATIO_TOL_L2 = 1.06
+# LevelBalanced since round 5: no tile levels, far sources at least four tiles back (MLZ_OPT_L2_GAP = 4: the decoder settles four tiles of a block side by
+# side); measured 1.003 / 0.950 / 1.056 / 1.067 x the oracle's L2 (with sources anywhere, round 4: 0.989 / 0.925 / 1.048 / 1.057)
+RATIO_TOL_L2 = {"enwik": 1.02, "text": 1.00, "json": 1.06, "json_text": 1.08, "twain": 1.08}
 RATIO_TOL_L2_LEVELS = 1.12
 RATIO_TOL_L0 = 1.10   # (text streams 0.87 - 0.90; the config-3 JSON stream 1.084: no far tables at this level)
 RATIO_TOL_64K = 1.08
@@ -127,7 +129,7 @@ def test_ratio_within_tolerance_of_reference_l1(ctx, kind):
     enc2 = roundtrip(d, ctx, level=2)
     ref2 = O.encode(d, 2)
     assert len(enc2) <= len(enc), (len(enc2), len(enc))
-    assert len(enc2) <= RATIO_TOL_L2 * len(ref2), (len(enc2), len(ref2))
+    assert len(enc2) <= RATIO_TOL_L2[kind] * len(ref2), (len(enc2), len(ref2))
     # ... and with the tile levels of rounds 1-3 (MLZ_OPT_L2_FREE = 0: level-scheduled decode, 8-9 % more output)
     ctx.set_option(mz.OPT_L2_FREE, 0)
     try:

@@ -90,6 +90,7 @@ struct Params {
                       // 2: own-phase compares — a lane compares 8 raw dwords = 32 - (p & 3) bytes, and far candidates below position 4 are not used (their
                       // bytes are loaded at q - (p & 3)).  1: in addition the four windows of an iteration are the four PHASES — window k = positions
                       // cur + 4 l + k —, all look-ups of the iteration come before its inserts (inserts window by window, lanes in order).
+    int min_tiles;    // no tile levels: a far source lies at least this many tiles back (MLZ_OPT_L2_GAP; 0 / 1 = anywhere)
     int near_unit;    // graded near tables: entries per 8 KiB of indexed positions (0: 2^near_bits / sub; the kernels' 12-bit class in phase-major form: 992)
 };
 
@@ -137,7 +138,7 @@ size_t model2_block(const uint8_t* src, size_t n, const Params* P, uint8_t* out,
     const int x_pmcap = getenv("MODEL_PMCAP") ? atoi(getenv("MODEL_PMCAP")) : P->pm != 0;
     // MODEL_MINTILES=K (round 5, with no tile levels): a far source lies at least K tiles back (or in the own tile: near matches) — K consecutive tiles of a
     // block then never read each other and a decoder could settle them side by side
-    const uint32_t x_mintiles = getenv("MODEL_MINTILES") ? uint32_t(atoi(getenv("MODEL_MINTILES"))) : 1;
+    const uint32_t x_mintiles = getenv("MODEL_MINTILES") ? uint32_t(atoi(getenv("MODEL_MINTILES"))) : (x_nolevel && P->min_tiles > 1 ? uint32_t(P->min_tiles) : 1u);
     const int x_l0pieces = getenv("MODEL_L0PIECES") ? atoi(getenv("MODEL_L0PIECES")) : 0;   // 1: the four 8 KiB pieces of a level-0 tile do not see each other (no seeding, no source before the piece)
     uint32_t x_minoff[4] = {0, 0, 0, 0};
     if (getenv("MODEL_MINOFF")) sscanf(getenv("MODEL_MINOFF"), "%u,%u,%u", &x_minoff[0], &x_minoff[1], &x_minoff[2]);

@@ -9,14 +9,14 @@ subprocess.check_call(['g++', '-O2', '-shared', '-fPIC', '-o', so, os.path.join(
 L = C.CDLL(so)
 FIELDS = 'sub nw near_bits lazy use_rep far lane_cap back dense skip_shift far_gate seed lazy_cost min_far probe_stride far_stride2 lazy_local far_hash24 far_prev'.split()
 class P(C.Structure):
-    _fields_ = [(k, C.c_int) for k in FIELDS] + [('pattern', C.c_uint), ('graded', C.c_int), ('far_bits', C.c_int), ('far_stride', C.c_int), ('seed_stride', C.c_int), ('pm', C.c_int), ('near_unit', C.c_int)]
+    _fields_ = [(k, C.c_int) for k in FIELDS] + [('pattern', C.c_uint), ('graded', C.c_int), ('far_bits', C.c_int), ('far_stride', C.c_int), ('seed_stride', C.c_int), ('pm', C.c_int), ('min_tiles', C.c_int), ('near_unit', C.c_int)]
 L.model2_block.restype = C.c_size_t
 L.model2_block.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(P), C.c_void_p, C.c_void_p]
-DEF = dict(sub=4, nw=4, near_bits=12, lazy=3, use_rep=0, far=1, lane_cap=32, back=8, dense=1, skip_shift=10, far_gate=0, seed=1, lazy_cost=1, min_far=8, probe_stride=1, far_stride2=0, lazy_local=1, far_hash24=2, far_prev=0, pattern=0xA9A9A994, graded=1, far_bits=17, far_stride=4, seed_stride=2, pm=int(os.environ.get('MODEL_PMV', '0')), near_unit=992 if os.environ.get('MODEL_PMV') == '1' else 0)  # = the kernels' defaults for blocks of 1 MiB and more (smaller blocks: near_bits=13, see def_for)
+DEF = dict(sub=4, nw=4, near_bits=12, lazy=3, use_rep=0, far=1, lane_cap=32, back=8, dense=1, skip_shift=10, far_gate=0, seed=1, lazy_cost=1, min_far=8, probe_stride=1, far_stride2=0, lazy_local=1, far_hash24=2, far_prev=0, pattern=0xA9A9A994, graded=1, far_bits=17, far_stride=4, seed_stride=2, pm=int(os.environ.get('MODEL_PMV', '0')), min_tiles=0, near_unit=992 if os.environ.get('MODEL_PMV') == '1' else 0)  # = the kernels' defaults for blocks of 1 MiB and more (smaller blocks: near_bits=13, see def_for)
 
 # LevelBalanced: 13-bit near tables seeded with every earlier position, far tables twice as dense and twice as large, the
 # previous epoch's table probed as well
-DEF_L2 = dict(DEF, near_bits=13, near_unit=0, far_prev=1, far_bits=18, far_stride=2, seed_stride=1, pattern=0xffffffff)   # pattern 0xffffffff = no tile levels (LevelBalanced's default since round 4); 0 = the dense four-level pattern (option 14 = 0)
+DEF_L2 = dict(DEF, near_bits=13, near_unit=0, far_prev=1, far_bits=18, far_stride=2, seed_stride=1, pattern=0xffffffff, min_tiles=4)   # pattern 0xffffffff = no tile levels (LevelBalanced's default since round 4); 0 = the dense four-level pattern (option 14 = 0)
 DEF_L2_LEVELS = dict(DEF_L2, pattern=0)
 
 def small_far_bits(nbytes, shift=2):

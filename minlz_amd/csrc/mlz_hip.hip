@@ -433,6 +433,12 @@ int encode_device_group(mlz_ctx* c, hipStream_t st, int level, const uint8_t* d_
     return 0;
 }
 
+// dec_general_kernel's role S workgroups: up to four per block (teams, GenCtl::team), at most a quarter of the device; a multiple of 4
+uint32_t gen_settle_wgs(mlz_ctx* c, int n) {
+    const uint32_t grid = c->gen_grid > 0 ? uint32_t(c->gen_grid) : uint32_t(c->n_cus);
+    return std::max<uint32_t>(4u, std::min<uint32_t>(4u * uint32_t(n), grid / 4) & ~3u);
+}
+
 int decode_parallel(mlz_ctx* c, hipStream_t st, const uint8_t* d_src, uint8_t* d_dst, const mlz_block_desc* desc, int n, int64_t* d_out_len,
                     bool raw_body, const uint64_t* mirror) {
     uint32_t tiles = 0, segs = 0;
@@ -541,11 +547,20 @@ int decode_parallel(mlz_ctx* c, hipStream_t st, const uint8_t* d_src, uint8_t* d
                                    tile_start, reg_out, reg_last, reg_entry, seg_ntok, tok_pos, round_d, round_rep,
                                    jump ? &gen->n_general : nullptr);
         }
-        // (+ the per-block gather of the index pass's verdict bytes: D3 / 3)
-        const bool gather_viol = segs && !c->index_passes;
+        if (jump && segs && !c->gen_attr) {
+            HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(dec_general_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kGenLds));
+            // how many of its workgroups the device holds at once (1024 threads + 132 KiB of LDS: one per CU).  Not a correctness
+            // requirement — role E never waits and role S only waits for role E, whose workgroups come first in the grid —: it
+            // sizes the grid so that the settling workgroups start beside the explaining ones instead of behind them.
+            int per_cu = 0;
+            HIPCHK(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(dec_general_kernel), kGenThreads, kGenLds));
+            c->gen_grid = per_cu >= 1 ? c->n_cus * per_cu : 0;
+            c->gen_attr = true;
+        }
+        if (segs && !c->index_passes)
+            hipLaunchKernelGGL(dec_viol_kernel, dim3((segs + 255) / 256), dim3(256), 0, st, seg_block, ws + o_sviol, dec, jump ? &gen->n_general : nullptr, segs);
         if (tiles) hipLaunchKernelGGL(dec_schedule_kernel, dim3(1), dim3(1024), 0, st, blocks, tile_block, dec, order, tiles, uint32_t(n),
-                                      jump ? reinterpret_cast<uint32_t*>(ws + o_glist) : nullptr, reinterpret_cast<uint32_t*>(gen), seg_block,
-                                      gather_viol ? ws + o_sviol : nullptr, segs, jump ? &gen->n_general : nullptr);
+                                      jump ? reinterpret_cast<uint32_t*>(ws + o_glist) : nullptr, reinterpret_cast<uint32_t*>(gen), gen_settle_wgs(c, n));
     }
     if (c->debug_stop) { HIPCHK(c, hipGetLastError()); return 0; }
     {
@@ -558,20 +573,9 @@ int decode_parallel(mlz_ctx* c, hipStream_t st, const uint8_t* d_src, uint8_t* d
     {
         Timer tg(c, T_DEC_GENERAL, st);   // (+ the result pass)
         if (jump && segs) {  // returns at once unless D3c flagged a general block
-            if (!c->gen_attr) {
-                HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(dec_general_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kGenLds));
-                // how many of its workgroups the device holds at once (1024 threads + 132 KiB of LDS: one per CU).  Not a correctness
-                // requirement — role E never waits and role S only waits for role E, whose workgroups come first in the grid —: it
-                // sizes the grid so that the settling workgroups start beside the explaining ones instead of behind them.
-                int per_cu = 0;
-                HIPCHK(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(dec_general_kernel), kGenThreads, kGenLds));
-                c->gen_grid = per_cu >= 1 ? c->n_cus * per_cu : 0;
-                c->gen_attr = true;
-            }
             if (c->gen_grid == 0) { c->err = "dec_general_kernel: the device cannot hold a workgroup"; return -MLZ_ERR_HIP; }
             // role S: one workgroup per general block, at most a quarter of the device (more blocks take turns); role E: the rest
-            // (a multiple of 4: blocks whose tiles do not read their nearest neighbours are settled by teams of 2 or 4 workgroups, GenCtl::team)
-            const uint32_t nS = std::max<uint32_t>(4u, std::min<uint32_t>(4u * uint32_t(n), uint32_t(c->gen_grid) / 4) & ~3u);
+            const uint32_t nS = gen_settle_wgs(c, n);
             const uint32_t nE = std::max<uint32_t>(1u, uint32_t(c->gen_grid) > nS ? uint32_t(c->gen_grid) - nS : 1u);
             hipLaunchKernelGGL(dec_general_kernel, dim3(nE + nS), dim3(kGenThreads), kGenLds, st, d_src, d_dst, blocks, dec, tok_pos, round_d, round_rep, tile_start,
                                reinterpret_cast<const uint32_t*>(ws + o_glist), c->d_idx.as<uint16_t>(), c->d_idx.as<uint8_t>() + (size_t(tiles) << kTileLog) * 2,

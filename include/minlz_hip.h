@@ -168,7 +168,8 @@ const char* mlz_timer_name(int idx);
  * general-block path (mlz_decode_general.hip.inc): the reference's own blocks, and this library's LevelBalanced ones.
  *            (of a batch that ran as several internal groups: those of its last group).
  * which = 3 / 4: bytes of device workspace the context holds for encoding / decoding (grow-only: the high-water mark so far).
- * which = 5: decode calls whose general blocks fell back to the tile chain because the general pass's buffers could not be allocated. */
+ * which = 5: decode calls whose general blocks fell back to the tile chain because the general pass's buffers could not be allocated.
+ * which = 6: workgroups per block (1, 2 or 4) the general-block pass of the last decode call settled with; 0 = it had no general block. */
 int64_t mlz_get_counter(mlz_ctx* ctx, int which);
 
 #ifdef __cplusplus

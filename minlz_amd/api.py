@@ -107,6 +107,10 @@ class Context:
         """Blocks of the last decode call that took the path for streams of other encoders (mlz_get_counter 2)."""
         return int(_lib.lib().mlz_get_counter(self.handle, 2))
 
+    def general_team(self):
+        """Workgroups per block (1, 2 or 4) the general-block pass of the last decode call settled with; 0 = no general block (mlz_get_counter 6)."""
+        return int(_lib.lib().mlz_get_counter(self.handle, 6))
+
     # ---- device-resident batch calls: pointers are raw device addresses (e.g. tensor.data_ptr()) ----
     def encode_batch_device(self, stream, level, d_src, d_dst, descs, d_out_len):
         arr = (BlockDesc * len(descs))(*descs) if not isinstance(descs, C.Array) else descs

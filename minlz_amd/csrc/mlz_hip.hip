@@ -1028,6 +1028,14 @@ int64_t mlz_get_counter(mlz_ctx* c, int which) {
         return int64_t(which == 3 ? e : d);
     }
     if (which == 5) { std::lock_guard<std::mutex> lk(c->mu); return int64_t(c->gen_fallbacks); }
+    if (which == 6) {  // workgroups per block (1, 2 or 4) the general pass of the last decode call settled with (waits for the device; of a batch in several groups: the last group's)
+        std::lock_guard<std::mutex> lk(c->mu);
+        if (!c->last_gen) return 0;
+        uint32_t v[5] = {0, 0, 0, 0, 0};
+        if (hipSetDevice(c->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess ||
+            hipMemcpy(v, c->last_gen, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) return -MLZ_ERR_HIP;
+        return v[0] ? int64_t(v[4]) : 0;
+    }
     std::lock_guard<std::mutex> lk(c->q_mu);
     return which == 0 ? int64_t(c->q_batches) : which == 1 ? int64_t(c->q_requests) : -MLZ_ERR_ARG;
 }

@@ -580,9 +580,9 @@ int decode_parallel(mlz_ctx* c, hipStream_t st, const uint8_t* d_src, uint8_t* d
             hipLaunchKernelGGL(dec_general_kernel, dim3(nE + nS), dim3(kGenThreads), kGenLds, st, d_src, d_dst, blocks, dec, tok_pos, round_d, round_rep, tile_start,
                                reinterpret_cast<const uint32_t*>(ws + o_glist), c->d_idx.as<uint16_t>(), c->d_idx.as<uint8_t>() + (size_t(tiles) << kTileLog) * 2,
                                reinterpret_cast<ExtEnt*>(c->d_idx.as<uint8_t>() + map_bytes), reinterpret_cast<GenTile*>(ws + o_xcnt), tile_done, gen, nE, nS,
-                               c->gen_spin_limit, uint32_t(c->gen_force_packed));
-        }
-        hipLaunchKernelGGL(dec_finish_kernel, dim3((n + 63) / 64), dim3(64), 0, st, dec, d_out_len, n, c->debug_status);
+                               c->gen_spin_limit, uint32_t(c->gen_force_packed), d_out_len, n, c->debug_status);   // (+ the results: D5)
+        } else
+            hipLaunchKernelGGL(dec_finish_kernel, dim3((n + 63) / 64), dim3(64), 0, st, dec, d_out_len, n, c->debug_status);
     }
     HIPCHK(c, hipGetLastError());
     return 0;
@@ -1031,10 +1031,10 @@ int64_t mlz_get_counter(mlz_ctx* c, int which) {
     if (which == 6) {  // workgroups per block (1, 2 or 4) the general pass of the last decode call settled with (waits for the device; of a batch in several groups: the last group's)
         std::lock_guard<std::mutex> lk(c->mu);
         if (!c->last_gen) return 0;
-        uint32_t v[5] = {0, 0, 0, 0, 0};
+        uint32_t v[6] = {0, 0, 0, 0, 0, 0};   // GenCtl
         if (hipSetDevice(c->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess ||
             hipMemcpy(v, c->last_gen, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) return -MLZ_ERR_HIP;
-        return v[0] ? int64_t(v[4]) : 0;
+        return v[0] ? int64_t(v[5]) : 0;
     }
     std::lock_guard<std::mutex> lk(c->q_mu);
     return which == 0 ? int64_t(c->q_batches) : which == 1 ? int64_t(c->q_requests) : -MLZ_ERR_ARG;

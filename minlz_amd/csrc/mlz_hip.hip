@@ -125,6 +125,7 @@ struct mlz_ctx {
     uint32_t gen_spin_limit = 1u << 24;  // role S's patience with a tile's ready flag, in polls (~0.3 us each): ~5 s
     int n_cus = 0;
     int far_slices_l2 = 0;     // debug option 18: 1 = LevelBalanced's far tables by far_build_kernel (slice workgroups, round 4) even without level sets
+    int gen_settle_cap = 0;    // debug option 20: settling workgroups of dec_general_kernel at most (0 = a quarter of the device)
     int l2_gap = 4;            // option 19: LevelBalanced without levels: a far source lies at least this many tiles back (1 = anywhere; 4: the decoder settles four tiles of a block side by side)
     int l2_free = 1;           // option 14 (default on): LevelBalanced without the tile-level constraint (better ratio; its blocks decode through the general path)
     uint64_t gen_fallbacks = 0;  // decode calls whose general blocks took the tile chain because the general pass's buffers could not be allocated (mlz_get_counter 5)
@@ -436,7 +437,8 @@ int encode_device_group(mlz_ctx* c, hipStream_t st, int level, const uint8_t* d_
 // dec_general_kernel's role S workgroups: up to four per block (teams, GenCtl::team), at most a quarter of the device; a multiple of 4
 uint32_t gen_settle_wgs(mlz_ctx* c, int n) {
     const uint32_t grid = c->gen_grid > 0 ? uint32_t(c->gen_grid) : uint32_t(c->n_cus);
-    return std::max<uint32_t>(4u, std::min<uint32_t>(4u * uint32_t(n), grid / 4) & ~3u);
+    const uint32_t cap = c->gen_settle_cap > 0 ? uint32_t(c->gen_settle_cap) : grid / 4;
+    return std::max<uint32_t>(4u, std::min<uint32_t>(4u * uint32_t(n), cap) & ~3u);
 }
 
 int decode_parallel(mlz_ctx* c, hipStream_t st, const uint8_t* d_src, uint8_t* d_dst, const mlz_block_desc* desc, int n, int64_t* d_out_len,
@@ -972,6 +974,7 @@ int mlz_set_option(mlz_ctx* c, int opt, int64_t value) {
     case MLZ_OPT_DEVICE_GROUP: c->device_group = size_t(value > 0 ? value : 1) << 20; return 0;  // MiB of uncompressed data per internal group of a device batch
     case 18: c->far_slices_l2 = int(value); return 0;  // debug / cross-check: LevelBalanced's far tables by the slice kernel of round 4
     case MLZ_OPT_L2_GAP: if (value < 1 || value > 16) return -MLZ_ERR_ARG; c->l2_gap = int(value); return 0;
+    case 20: c->gen_settle_cap = int(value); return 0;  // tuning: role S workgroups of the general pass at most
     case 14: c->l2_free = int(value); return 0;  // LevelBalanced: 1 = no tile levels (ratio of the reference's L2 and better; blocks decode as general blocks)
     case 13: c->gen_force_packed = int(value); return 0;  // tests: general blocks settle through the byte-packed pool (fallback path of dec_general_kernel)
     case 9: c->gen_spin_limit = value > 0 ? uint32_t(value) : 1u; return 0;  // grid-barrier patience of the general-block pass, in polls (tests)

@@ -6,7 +6,10 @@ from minlz_amd._lib import BlockDesc
 B=8<<20
 host=synth.json_like(100_000_000, 77)
 dev=torch.device("cuda",0); ctx=mz.Context(0)
-for nblk in (12, 24, 64, 128):
+import os
+if os.environ.get('SETTLE_CAP'): ctx.set_option(20, int(os.environ['SETTLE_CAP']))
+BLOCKS=[int(x) for x in os.environ.get('BLOCKS','12,24,64,128').split(',')]
+for nblk in BLOCKS:
     S=nblk*B
     src=torch.from_numpy(host).to(dev).repeat((S+host.size-1)//host.size)[:S].contiguous()
     stride=B+256

@@ -97,7 +97,8 @@ int mlz_decode_batch(mlz_ctx* ctx, int n_blocks, const uint8_t* const* src, cons
  * d_src / d_dst / d_out_len are device pointers.  d_out_len[i] (int64) receives what
  * mlz_encode / mlz_decode would have returned for block i.  `desc` is a host array (copied).
  * A context owns ONE workspace: calls issued on different streams are ordered on the device (each waits for the
- * previous call's last kernel through an event), so they are safe but do not overlap; use one context per stream
+ * previous call's last kernel through an event, recorded when a call arrives on a stream other than the last one's: a stream that was
+ * used for a call must stay alive until the context's next call or mlz_destroy), so they are safe but do not overlap; use one context per stream
  * for concurrency.
  * Workspace: a batch runs in internal groups of about 512 MiB of uncompressed data (MLZ_OPT_DEVICE_GROUP; at least one block per group;
  * throughput is flat from 64 blocks of 8 MiB on), one after the other on `stream`, so the workspace is bounded by the group, not by the

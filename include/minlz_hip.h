@@ -59,6 +59,27 @@ typedef struct {
  * reference (its kernels need no state beyond sync.Pool tables, encode_amd64.go:119-189). */
 int mlz_init(int device, mlz_ctx** out);
 void mlz_destroy(mlz_ctx* ctx);
+/* Several devices behind ONE context, in one process (the reference's Writer and Reader fan the blocks of a stream out to goroutines inside
+ * one process: writer.go:501-560, in-order emit writer.go:219-272, reader.go:830-859 — a Go host is one process, so the fan-out over the GPUs
+ * of a node sits behind this ABI, not above it).  devices[0 .. n_devices): HIP device ordinals, one per-device context each (an ordinal may be
+ * repeated: two contexts on one GPU overlap one's copies with the other's kernels, and it is how the path is tested on a one-GPU box);
+ * devices == NULL: every visible device (n_devices > 0: the first n_devices of them).
+ * With such a context
+ *   mlz_encode_batch / mlz_decode_batch   deal contiguous block ranges of about equal bytes to the devices, one host thread and one PCIe link per
+ *                                          device; every result lands at the caller's dst[i] (page-locked destinations are written by the kernels of
+ *                                          whichever device ran the block), so there is nothing to gather and no collective;
+ *   mlz_stream_encode                      deals contiguous block ranges the same way; a range's chunks go to their final place in dst once the sizes
+ *                                          of the ranges before it are known (the in-order emit); the stream is byte-identical to the one-device call's;
+ *   mlz_stream_decode                      deals contiguous chunk ranges of about equal output (every chunk's output offset is known from the chunk walk);
+ *   mlz_encode / mlz_decode / *_block / mlz_crc   go to the devices in turn, each with its own combining queue;
+ *   the *_batch_device calls               run on the device that holds d_src (-MLZ_ERR_ARG if none of the context's devices does);
+ *   mlz_stream_encode_gather_device        (below) is the device-resident form: sources in each device's HBM, the framed stream gathered GPU-to-GPU;
+ *   mlz_set_option applies to every device, mlz_get_counter sums (which = 6: the maximum), mlz_get_timers reports the slowest device per family.
+ * A context from mlz_init behaves as before everywhere (mlz_device_count = 1).  mlz_device_ctx(ctx, i) is the i-th per-device context — owned by
+ * ctx, valid until mlz_destroy(ctx) — for callers that place device-resident work themselves. */
+int mlz_init_devices(const int* devices, int n_devices, mlz_ctx** out);
+int mlz_device_count(mlz_ctx* ctx);
+mlz_ctx* mlz_device_ctx(mlz_ctx* ctx, int i);
 const char* mlz_last_error(mlz_ctx* ctx); /* text of the last HIP failure on this context */
 /* Library/ABI version and the name of the device the context runs on. */
 int mlz_version(void);
@@ -169,11 +190,12 @@ const char* mlz_timer_name(int idx);
  * mlz_decode_block): concurrent callers — one goroutine per block in the reference's Writer/Reader, writer.go:501-560,
  * reader.go:830-859 — are run as one batched launch.  which: 0 = batches run, 1 = requests served.
  * which = 2: blocks of the last decode call that matched no tile-level pattern of this library's encoder and went through the
- * general-block path (mlz_decode_general.hip.inc): the reference's own blocks, and this library's LevelBalanced ones.
- *            (of a batch that ran as several internal groups: those of its last group).
+ * general-block path (mlz_decode_general.hip.inc): the reference's own blocks, and this library's LevelBalanced ones
+ *            (summed over the internal groups a batch ran as).
  * which = 3 / 4: bytes of device workspace the context holds for encoding / decoding (grow-only: the high-water mark so far).
  * which = 5: decode calls whose general blocks fell back to the tile chain because the general pass's buffers could not be allocated.
- * which = 6: workgroups per block (1, 2 or 4) the general-block pass of the last decode call settled with; 0 = it had no general block. */
+ * which = 6: workgroups per block (1, 2 or 4) the general-block pass of the last decode call settled with (the largest over its internal groups);
+ *            0 = it had no general block. */
 int64_t mlz_get_counter(mlz_ctx* ctx, int which);
 
 #ifdef __cplusplus

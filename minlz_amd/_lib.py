@@ -15,7 +15,7 @@ SYMBOLS = [
     "mlz_decoded_len", "mlz_encode", "mlz_decode", "mlz_encode_block", "mlz_decode_block", "mlz_encode_batch",
     "mlz_decode_batch", "mlz_encode_batch_device", "mlz_decode_batch_device", "mlz_set_option", "mlz_get_timers",
     "mlz_timer_name", "mlz_crc", "mlz_crc_batch_device", "mlz_stream_bound", "mlz_stream_encode", "mlz_stream_decoded_len",
-    "mlz_stream_decode", "mlz_get_counter",
+    "mlz_stream_decode", "mlz_get_counter", "mlz_init_devices", "mlz_device_count", "mlz_device_ctx",
 ]
 
 
@@ -36,6 +36,9 @@ def lib():
     vp, sz, i64, i32 = C.c_void_p, C.c_size_t, C.c_int64, C.c_int
     L.mlz_init.argtypes = [i32, C.POINTER(vp)]; L.mlz_init.restype = i32
     L.mlz_destroy.argtypes = [vp]; L.mlz_destroy.restype = None
+    L.mlz_init_devices.argtypes = [C.POINTER(i32), i32, C.POINTER(vp)]; L.mlz_init_devices.restype = i32
+    L.mlz_device_count.argtypes = [vp]; L.mlz_device_count.restype = i32
+    L.mlz_device_ctx.argtypes = [vp, i32]; L.mlz_device_ctx.restype = vp
     L.mlz_last_error.argtypes = [vp]; L.mlz_last_error.restype = C.c_char_p
     L.mlz_version.argtypes = []; L.mlz_version.restype = i32
     L.mlz_device_name.argtypes = [vp, C.c_char_p, sz]; L.mlz_device_name.restype = i32

@@ -61,11 +61,24 @@ def _raise(code, ctx=None):
 class Context:
     """One HIP device context (mlz_ctx). Thread-safe on the C side."""
 
-    def __init__(self, device=-1):
+    def __init__(self, device=-1, devices=None):
+        """device: one HIP device (mlz_init).  devices: a list of ordinals (repeats allowed) or "all" — one context that deals the blocks of
+        batches and streams to all of them from this process (mlz_init_devices)."""
         self.handle = C.c_void_p()
-        r = _lib.lib().mlz_init(device, C.byref(self.handle))
+        L = _lib.lib()
+        if devices is None:
+            r = L.mlz_init(device, C.byref(self.handle))
+        elif isinstance(devices, str):
+            assert devices == "all"
+            r = L.mlz_init_devices(None, 0, C.byref(self.handle))
+        else:
+            arr = (C.c_int * len(devices))(*devices)
+            r = L.mlz_init_devices(arr, len(devices), C.byref(self.handle))
         if r != 0:
             raise ErrHIP("mlz_init failed (%d): no HIP device?" % r)
+
+    def device_count(self):
+        return int(_lib.lib().mlz_device_count(self.handle))
 
     def close(self):
         if self.handle:

@@ -6,11 +6,13 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <condition_variable>
 #include <cstdio>
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <type_traits>
 #include <vector>
 
@@ -75,6 +77,11 @@ constexpr size_t kHostGroupEncodeDefault = 32u << 20, kHostGroupDecodeDefault = 
 
 struct mlz_ctx {
     int device = 0;
+    // mlz_init_devices: the per-device contexts this one deals blocks to.  Such a context owns no device state of its own: every entry point
+    // either fans out over `kids` (batches, streams), hands a single-block call to one of them in turn, or routes a device-resident call to the
+    // kid whose device holds the buffers.
+    std::vector<mlz_ctx*> kids;
+    std::atomic<uint32_t> rr{0};
     std::mutex mu;
     // combining queue of the single-block host calls
     std::mutex q_mu;
@@ -84,7 +91,8 @@ struct mlz_ctx {
     uint64_t q_batches = 0, q_requests = 0;  // mlz_get_counter
     int index_passes = 0;                    // MLZ_OPT_INDEX_PASSES
     int debug_stop = 0;                      // debug option 16: decode stops after the index pass (timing experiments with broken kernel variants)
-    void* last_gen = nullptr;                // GenCtl of the last decode call (device memory)
+    void* last_gen = nullptr;                // GenCtl of the last decode call's last group (device memory)
+    uint64_t acc_call = 0;                   // the call_seq whose first group has reset d_gen_acc
     std::string err;
     std::string dev_name;
     hipStream_t stream = nullptr;  // used by the host-pointer calls
@@ -119,6 +127,7 @@ struct mlz_ctx {
     bool farbin_attr = false;
     // decode workspace
     DevBuf d_dec, d_idx;
+    DevBuf d_gen_acc;      // two words summed over a call's internal groups by dec_schedule_kernel: general blocks, largest team (mlz_get_counter 2 / 6)
     int general_algo = 0;  // 0 = pointer-jumping pass for general blocks, 1 = tile chain in the exec pass
     size_t host_group_enc = kHostGroupEncodeDefault, host_group_dec = kHostGroupDecodeDefault;  // host-pointer batches: bytes per overlapped group
     int gen_grid = 0;      // workgroups of dec_general_kernel the device holds at once
@@ -566,8 +575,14 @@ int decode_parallel(mlz_ctx* c, hipStream_t st, const uint8_t* d_src, uint8_t* d
         }
         if (segs && !c->index_passes)
             hipLaunchKernelGGL(dec_viol_kernel, dim3((segs + 255) / 256), dim3(256), 0, st, seg_block, ws + o_sviol, dec, jump ? &gen->n_general : nullptr, segs);
-        if (tiles) hipLaunchKernelGGL(dec_schedule_kernel, dim3(1), dim3(1024), 0, st, blocks, tile_block, dec, order, tiles, uint32_t(n),
-                                      jump ? reinterpret_cast<uint32_t*>(ws + o_glist) : nullptr, reinterpret_cast<uint32_t*>(gen), gen_settle_wgs(c, n));
+        if (tiles) {
+            HIPCHK(c, c->d_gen_acc.ensure(64));
+            const uint32_t reset = c->acc_call != c->call_seq ? 1u : 0u;
+            c->acc_call = c->call_seq;
+            hipLaunchKernelGGL(dec_schedule_kernel, dim3(1), dim3(1024), 0, st, blocks, tile_block, dec, order, tiles, uint32_t(n),
+                               jump ? reinterpret_cast<uint32_t*>(ws + o_glist) : nullptr, reinterpret_cast<uint32_t*>(gen), gen_settle_wgs(c, n),
+                               c->d_gen_acc.as<uint32_t>(), reset);
+        }
     }
     if (c->debug_stop) { HIPCHK(c, hipGetLastError()); return 0; }
     {
@@ -806,11 +821,71 @@ void submit_single(mlz_ctx* c, SingleReq& rq) {
     }
 }
 
+// The contexts a host-pointer call is dealt to: the context itself, or the per-device contexts behind it (mlz_init_devices).
+struct Workers {
+    mlz_ctx* one;
+    mlz_ctx* const* list;
+    size_t n;
+    explicit Workers(mlz_ctx* c) : one(c), list(&one), n(1) {
+        if (!c->kids.empty()) { list = c->kids.data(); n = c->kids.size(); }
+    }
+    mlz_ctx* next() const { return n == 1 ? list[0] : list[one->rr.fetch_add(1, std::memory_order_relaxed) % n]; }   // single-block calls: the kids in turn
+};
+
+// The kid whose device holds `p` (a device-resident call on a several-device context), or the context itself.
+mlz_ctx* owner_of(mlz_ctx* c, const void* p) {
+    if (c->kids.empty()) return c;
+    hipPointerAttribute_t at;
+    if (p && hipPointerGetAttributes(&at, p) == hipSuccess && at.type == hipMemoryTypeDevice) {
+        for (mlz_ctx* k : c->kids) if (k->device == at.device) return k;
+        return nullptr;
+    }
+    (void)hipGetLastError();
+    return nullptr;
+}
+
+// A host-pointer batch over several devices: contiguous block ranges of about equal weight, one thread and one PCIe link per device,
+// every range through host_batch on its own context (the reference fans the blocks of a stream to goroutines, writer.go:501-560,
+// reader.go:830-859; results land at the caller's dst[i] whatever device produced them, so there is nothing to gather).
+int multi_host_batch(mlz_ctx* c, bool encode, int level, int n, const uint8_t* const* src, const size_t* src_len, uint8_t* const* dst, const size_t* dst_cap,
+                     int64_t* out_len) {
+    Workers w(c);
+    if (w.n == 1) return host_batch(w.list[0], encode, level, n, src, src_len, dst, dst_cap, out_len, true, nullptr);
+    std::vector<uint64_t> pre(size_t(n) + 1, 0);
+    for (int i = 0; i < n; i++) {
+        uint64_t wt = src_len[i];
+        if (!encode) { const int64_t dl = mlz_decoded_len(src[i], src_len[i]); if (dl > 0) wt += uint64_t(dl); }
+        pre[size_t(i) + 1] = pre[size_t(i)] + wt + 4096;
+    }
+    const uint64_t total = pre[size_t(n)];
+    size_t k = std::min<size_t>(w.n, size_t(n));
+    if (total < (uint64_t(4) << 20)) k = 1;    // not worth a second device
+    if (k == 1) return host_batch(w.next(), encode, level, n, src, src_len, dst, dst_cap, out_len, true, nullptr);
+    std::vector<int> cut(k + 1, n);
+    cut[0] = 0;
+    {
+        size_t j = 1;
+        for (int i = 0; i < n && j < k; i++)
+            while (j < k && pre[size_t(i) + 1] * k >= total * j) cut[j++] = i + 1;
+    }
+    std::vector<int> rcs(k, 0);
+    auto work = [&](size_t j) {
+        const int b0 = cut[j], cnt = cut[j + 1] - cut[j];
+        if (cnt > 0) rcs[j] = host_batch(w.list[j], encode, level, cnt, src + b0, src_len + b0, dst + b0, dst_cap + b0, out_len + b0, true, nullptr);
+    };
+    std::vector<std::thread> th;
+    for (size_t j = 1; j < k; j++) th.emplace_back(work, j);
+    work(0);
+    for (std::thread& t : th) t.join();
+    for (size_t j = 0; j < k; j++) if (rcs[j]) { c->err = w.list[j]->err; return rcs[j]; }
+    return 0;
+}
+
 }  // namespace
 
 extern "C" {
 
-int mlz_version(void) { return 1; }
+int mlz_version(void) { return 2; }
 
 int mlz_init(int device, mlz_ctx** out) {
     if (!out) return -MLZ_ERR_ARG;
@@ -836,11 +911,46 @@ int mlz_init(int device, mlz_ctx** out) {
     return 0;
 }
 
+int mlz_init_devices(const int* devices, int n_devices, mlz_ctx** out) {
+    if (!out || (devices && n_devices <= 0)) return -MLZ_ERR_ARG;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count == 0) return -MLZ_ERR_HIP;
+    std::vector<int> devs;
+    if (devices) devs.assign(devices, devices + n_devices);
+    else for (int d = 0; d < count && (n_devices <= 0 || d < n_devices); d++) devs.push_back(d);   // every visible device (or the first n_devices)
+    mlz_ctx* p = new mlz_ctx();
+    for (int d : devs) {
+        mlz_ctx* k = nullptr;
+        const int r = (d < 0 || d >= count) ? -MLZ_ERR_ARG : mlz_init(d, &k);
+        if (r) { for (mlz_ctx* q : p->kids) mlz_destroy(q); delete p; return r; }
+        p->kids.push_back(k);
+    }
+    p->device = p->kids[0]->device;
+    p->n_cus = p->kids[0]->n_cus;
+    p->dev_name = std::to_string(p->kids.size()) + " x " + p->kids[0]->dev_name;
+    *out = p;
+    return 0;
+}
+
+int mlz_device_count(mlz_ctx* c) { return !c ? -MLZ_ERR_ARG : c->kids.empty() ? 1 : int(c->kids.size()); }
+
+mlz_ctx* mlz_device_ctx(mlz_ctx* c, int i) {
+    if (!c || i < 0) return nullptr;
+    if (c->kids.empty()) return i == 0 ? c : nullptr;
+    return size_t(i) < c->kids.size() ? c->kids[size_t(i)] : nullptr;
+}
+
 void mlz_destroy(mlz_ctx* c) {
     if (!c) return;
+    if (!c->kids.empty()) {   // a several-device context: its kids hold everything
+        for (mlz_ctx* k : c->kids) mlz_destroy(k);
+        delete c;
+        return;
+    }
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
-    for (DevBuf* b : {&c->d_place, &c->d_crc, &c->d_crc_tabs, &c->d_crc_tiles, &c->d_prof, &c->d_blocks_k[0], &c->d_blocks_k[1], &c->d_tile_block_k[0], &c->d_tile_block_k[1], &c->d_seg_block_k[0], &c->d_seg_block_k[1], &c->d_scratch, &c->d_tile_size, &c->d_tile_out, &c->d_flags, &c->d_far, &c->d_farbin, &c->d_recs, &c->d_piece_cnt, &c->d_dec, &c->d_idx, &c->d_in, &c->d_out, &c->d_len})
+    for (DevBuf* b : {&c->d_place, &c->d_crc, &c->d_crc_tabs, &c->d_crc_tiles, &c->d_prof, &c->d_blocks_k[0], &c->d_blocks_k[1], &c->d_tile_block_k[0], &c->d_tile_block_k[1], &c->d_seg_block_k[0], &c->d_seg_block_k[1], &c->d_scratch, &c->d_tile_size, &c->d_tile_out, &c->d_flags, &c->d_far, &c->d_farbin, &c->d_recs, &c->d_piece_cnt, &c->d_dec, &c->d_idx, &c->d_gen_acc, &c->d_in, &c->d_out, &c->d_len})
         b->release();
     for (int k = 0; k < 2; k++) if (c->pinned_k[k]) (void)hipHostFree(c->pinned_k[k]);
     if (c->pinned2) (void)hipHostFree(c->pinned2);
@@ -857,7 +967,11 @@ void mlz_destroy(mlz_ctx* c) {
     delete c;
 }
 
-const char* mlz_last_error(mlz_ctx* c) { return c ? c->err.c_str() : "null context"; }
+const char* mlz_last_error(mlz_ctx* c) {
+    if (!c) return "null context";
+    if (c->err.empty()) for (mlz_ctx* k : c->kids) if (!k->err.empty()) return k->err.c_str();
+    return c->err.c_str();
+}
 
 int mlz_device_name(mlz_ctx* c, char* buf, size_t cap) {
     if (!c || !buf || cap == 0) return -MLZ_ERR_ARG;
@@ -893,7 +1007,7 @@ int64_t mlz_encode(mlz_ctx* c, int level, const uint8_t* src, size_t n, uint8_t*
     if (int64_t(dst_cap) < mlz_max_encoded_len(n)) return -MLZ_ERR_DST_TOO_SMALL;
     if (!valid_level(level)) return -MLZ_ERR_INVALID_LEVEL;
     SingleReq rq{true, true, false, level, src, n, dst, dst_cap, 0};
-    submit_single(c, rq);
+    submit_single(Workers(c).next(), rq);
     return rq.rc ? rq.rc : rq.out;
 }
 
@@ -903,7 +1017,7 @@ int64_t mlz_encode_block(mlz_ctx* c, int level, const uint8_t* src, size_t n, ui
     if (dst_cap < n) return -MLZ_ERR_DST_TOO_SMALL;
     if (!valid_level(level)) return -MLZ_ERR_INVALID_LEVEL;
     SingleReq rq{true, false, false, level, src, n, dst, dst_cap, 0};
-    submit_single(c, rq);
+    submit_single(Workers(c).next(), rq);
     return rq.rc ? rq.rc : rq.out;
 }
 
@@ -917,7 +1031,7 @@ int64_t mlz_decode(mlz_ctx* c, const uint8_t* src, size_t n, uint8_t* dst, size_
     (void)dl;
     if (dlen == 0) return 0;
     SingleReq rq{false, true, false, 0, src, n, dst, dst_cap, 0};
-    submit_single(c, rq);
+    submit_single(Workers(c).next(), rq);
     return rq.rc ? rq.rc : rq.out;
 }
 
@@ -926,7 +1040,7 @@ int mlz_decode_block(mlz_ctx* c, const uint8_t* src, size_t clen, uint8_t* dst, 
     if (n > kMaxBlockSize) return -MLZ_ERR_TOO_LARGE;
     if (n == 0) return clen == 0 ? 0 : 1;
     SingleReq rq{false, false, true, 0, src, clen, dst, n, n};
-    submit_single(c, rq);
+    submit_single(Workers(c).next(), rq);
     if (rq.rc) return rq.rc;
     if (rq.out == int64_t(n)) return 0;
     // Only a DEVICE failure (-MLZ_ERR_HIP: a launch that failed, a bounded wait that gave up) is passed on as < 0, the shim's cue
@@ -942,30 +1056,37 @@ int mlz_encode_batch(mlz_ctx* c, int level, int n, const uint8_t* const* src, co
     if (!c || n < 0) return -MLZ_ERR_ARG;
     if (n == 0) return 0;
     if (!valid_level(level)) return -MLZ_ERR_INVALID_LEVEL;
-    return host_batch(c, true, level, n, src, src_len, dst, dst_cap, out_len, true, nullptr);
+    return multi_host_batch(c, true, level, n, src, src_len, dst, dst_cap, out_len);
 }
 
 int mlz_decode_batch(mlz_ctx* c, int n, const uint8_t* const* src, const size_t* src_len, uint8_t* const* dst, const size_t* dst_cap, int64_t* out_len) {
     if (!c || n < 0) return -MLZ_ERR_ARG;
     if (n == 0) return 0;
-    return host_batch(c, false, 0, n, src, src_len, dst, dst_cap, out_len, true, nullptr);
+    return multi_host_batch(c, false, 0, n, src, src_len, dst, dst_cap, out_len);
 }
 
 int mlz_encode_batch_device(mlz_ctx* c, void* stream, int level, const uint8_t* d_src, uint8_t* d_dst, const mlz_block_desc* desc, int n,
                             int64_t* d_out_len) {
     if (!c || !desc || n < 0 || !d_out_len) return -MLZ_ERR_ARG;
+    if (!(c = owner_of(c, d_src))) return -MLZ_ERR_ARG;   // (several devices: the one that holds the buffers)
     std::lock_guard<std::mutex> lk(c->mu);
     return encode_device_locked(c, static_cast<hipStream_t>(stream), level, d_src, d_dst, desc, n, d_out_len, true);
 }
 
 int mlz_decode_batch_device(mlz_ctx* c, void* stream, const uint8_t* d_src, uint8_t* d_dst, const mlz_block_desc* desc, int n, int64_t* d_out_len) {
     if (!c || !desc || n < 0 || !d_out_len) return -MLZ_ERR_ARG;
+    if (!(c = owner_of(c, d_src))) return -MLZ_ERR_ARG;
     std::lock_guard<std::mutex> lk(c->mu);
     return decode_device_locked(c, static_cast<hipStream_t>(stream), d_src, d_dst, desc, n, d_out_len, false);
 }
 
 int mlz_set_option(mlz_ctx* c, int opt, int64_t value) {
     if (!c) return -MLZ_ERR_ARG;
+    if (!c->kids.empty()) {   // every device alike (the debug read-backs 5 / 7: the first device's)
+        if (opt == 5 || opt == 7) return mlz_set_option(c->kids[0], opt, value);
+        for (mlz_ctx* k : c->kids) { const int r = mlz_set_option(k, opt, value); if (r) return r; }
+        return 0;
+    }
     std::lock_guard<std::mutex> lk(c->mu);
     switch (opt) {
     case MLZ_OPT_DECODE_ALGO: c->decode_algo = int(value); return 0;
@@ -1020,13 +1141,24 @@ int mlz_set_option(mlz_ctx* c, int opt, int64_t value) {
 
 int64_t mlz_get_counter(mlz_ctx* c, int which) {
     if (!c) return -MLZ_ERR_ARG;
-    if (which == 2) {  // blocks of the last decode call that fit neither level pattern (waits for the device)
+    if (!c->kids.empty()) {   // sums over the devices (6, a team size: the largest)
+        int64_t acc = 0;
+        for (mlz_ctx* k : c->kids) {
+            const int64_t v = mlz_get_counter(k, which);
+            if (v < 0) return v;
+            acc = which == 6 ? std::max(acc, v) : acc + v;
+        }
+        return acc;
+    }
+    if (which == 2 || which == 6) {
+        // 2: blocks of the last decode call that fit no level pattern; 6: workgroups per block (1, 2 or 4) its general pass settled with (0 = no general block).
+        // Both over ALL internal groups of the call (sum / maximum, kept by dec_schedule_kernel); waits for the device.
         std::lock_guard<std::mutex> lk(c->mu);
-        if (!c->last_gen) return 0;
-        uint32_t v = 0;
+        if (!c->d_gen_acc.p) return 0;
+        uint32_t v[2] = {0, 0};
         if (hipSetDevice(c->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess ||
-            hipMemcpy(&v, c->last_gen, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) return -MLZ_ERR_HIP;
-        return int64_t(v);
+            hipMemcpy(v, c->d_gen_acc.p, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) return -MLZ_ERR_HIP;
+        return int64_t(which == 2 ? v[0] : (v[0] ? v[1] : 0));
     }
     if (which == 3 || which == 4) {  // device workspace this context holds: 3 = encode side, 4 = decode side (grow-only buffers: the high-water mark of the calls so far)
         std::lock_guard<std::mutex> lk(c->mu);
@@ -1036,20 +1168,23 @@ int64_t mlz_get_counter(mlz_ctx* c, int which) {
         return int64_t(which == 3 ? e : d);
     }
     if (which == 5) { std::lock_guard<std::mutex> lk(c->mu); return int64_t(c->gen_fallbacks); }
-    if (which == 6) {  // workgroups per block (1, 2 or 4) the general pass of the last decode call settled with (waits for the device; of a batch in several groups: the last group's)
-        std::lock_guard<std::mutex> lk(c->mu);
-        if (!c->last_gen) return 0;
-        uint32_t v[6] = {0, 0, 0, 0, 0, 0};   // GenCtl
-        if (hipSetDevice(c->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess ||
-            hipMemcpy(v, c->last_gen, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) return -MLZ_ERR_HIP;
-        return v[0] ? int64_t(v[5]) : 0;
-    }
     std::lock_guard<std::mutex> lk(c->q_mu);
     return which == 0 ? int64_t(c->q_batches) : which == 1 ? int64_t(c->q_requests) : -MLZ_ERR_ARG;
 }
 
 int mlz_get_timers(mlz_ctx* c, float* ms, int cap) {
     if (!c || !ms) return -MLZ_ERR_ARG;
+    if (!c->kids.empty()) {   // the devices work side by side: the slowest one's time per kernel family
+        int n = 0;
+        std::vector<float> t(size_t(std::max(cap, 0)));
+        for (int i = 0; i < cap; i++) ms[i] = -1.f;
+        for (mlz_ctx* k : c->kids) {
+            n = mlz_get_timers(k, t.data(), cap);
+            if (n < 0) return n;
+            for (int i = 0; i < n; i++) ms[i] = std::max(ms[i], t[size_t(i)]);
+        }
+        return n;
+    }
     std::lock_guard<std::mutex> lk(c->mu);
     int n = std::min<int>(cap, T_COUNT);
     for (int i = 0; i < n; i++) {
@@ -1064,12 +1199,14 @@ const char* mlz_timer_name(int idx) { return idx >= 0 && idx < T_COUNT ? kTimerN
 
 int mlz_crc_batch_device(mlz_ctx* c, void* stream, const uint8_t* d_base, const mlz_block_desc* desc, int n, uint32_t* d_out) {
     if (!c || !desc || n < 0 || !d_out) return -MLZ_ERR_ARG;
+    if (!(c = owner_of(c, d_base))) return -MLZ_ERR_ARG;
     std::lock_guard<std::mutex> lk(c->mu);
     return crc_device_locked(c, static_cast<hipStream_t>(stream), d_base, desc, n, d_out);
 }
 
 int64_t mlz_crc(mlz_ctx* c, const uint8_t* src, size_t n) {
     if (!c || (!src && n)) return -MLZ_ERR_ARG;
+    c = Workers(c).next();
     std::lock_guard<std::mutex> lk(c->mu);
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, c->d_in.ensure(n + 64));

@@ -105,3 +105,35 @@ def test_bench_refuses_a_world_it_cannot_start():
     assert r.returncode != 0
     assert "--gpus 2" in r.stderr and "GPU" in r.stderr
     assert "{" not in r.stdout          # no JSON line from a run that did not happen
+
+
+def _build_c_client(tmp_path):
+    """tests/c/abi_client.c: the header compiled as C99 by gcc (the compiler cgo runs on go/minlz_hip.go's preamble), linked against the library."""
+    import shutil
+    import subprocess
+    _build.build()
+    exe = str(tmp_path / "abi_client")
+    so_dir = os.path.dirname(_lib.SO)
+    cmd = [shutil.which("gcc") or "gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(ROOT, "include"),
+           os.path.join(ROOT, "tests", "c", "abi_client.c"), "-o", exe, "-L", so_dir, "-lminlz_hip", "-Wl,-rpath," + so_dir]
+    subprocess.check_call(cmd)
+    env = dict(os.environ)
+    env["LD_LIBRARY_PATH"] = "/opt/rocm/lib:" + env.get("LD_LIBRARY_PATH", "")
+    return exe, env
+
+
+def test_c_client_compiles_as_c99_and_runs_host_checks(tmp_path):
+    """No GPU here: the client's host-only checks pass and mlz_init's failure is the exit code 77 (on a GPU box it goes on and returns 0)."""
+    import subprocess
+    exe, env = _build_c_client(tmp_path)
+    p = subprocess.run([exe], env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode in (0, 77), (p.returncode, p.stderr)
+
+
+@pytest.mark.gpu
+def test_c_client_on_the_device(tmp_path):
+    """The whole C client on the GPU: Encode/Decode, block contracts, batches, streams on one device and on two contexts behind one handle."""
+    import subprocess
+    exe, env = _build_c_client(tmp_path)
+    p = subprocess.run([exe], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and "abi_client ok" in p.stdout, (p.returncode, p.stdout, p.stderr)

@@ -133,3 +133,46 @@ def test_timers_sum_over_the_groups():
         assert 0.8 * t1["enc_tiles"] < t3["enc_tiles"] < 6 * t1["enc_tiles"]
     finally:
         ctx.close()
+
+
+@pytest.mark.parametrize("level", [1, 2])
+@pytest.mark.parametrize("where", ["last", "middle"])
+def test_oversize_block_in_a_device_batch(level, where):
+    """A block above MaxBlockSize in a device batch is ITS OWN failure (-ErrTooLarge, encode.go:74-80) and nothing else's: it has no tiles,
+    and no kernel may read descriptors or units on its behalf (round-5 advisor finding: LevelBalanced's far_slice_kernel did)."""
+    import torch
+    dev = torch.device("cuda", 0)
+    big = (8 << 20) + 100
+    parts = [synth.json_like(1_500_000, seed=71), synth.text_like(2 << 20, seed=72)]
+    over = synth.text_like(big, seed=73)
+    parts.insert(1 if where == "middle" else 2, over)
+    offs, cur = [], 0
+    for p in parts:
+        offs.append(cur)
+        cur += p.size + 16
+    host = np.zeros(cur + 64, dtype=np.uint8)
+    for o, p in zip(offs, parts):
+        host[o:o + p.size] = p
+    src = torch.from_numpy(host).to(dev)
+    caps = [p.size + 2 for p in parts]
+    eoffs, ecur = [], 0
+    for c in caps:
+        eoffs.append(ecur)
+        ecur += c + 32
+    enc = torch.zeros(ecur + 64, dtype=torch.uint8, device=dev)
+    elen = torch.zeros(len(parts), dtype=torch.int64, device=dev)
+    ctx = mz.Context(0)
+    try:
+        st = torch.cuda.current_stream(dev).cuda_stream
+        ctx.encode_batch_device(st, level, src.data_ptr(), enc.data_ptr(), [BlockDesc(o, p.size, eo, c) for o, p, eo, c in zip(offs, parts, eoffs, caps)], elen.data_ptr())
+        torch.cuda.synchronize()
+        lens = elen.cpu().tolist()
+        eh = enc.cpu().numpy()
+        for i, p in enumerate(parts):
+            if p.size > (8 << 20):
+                assert lens[i] == -2, lens       # -MLZ_ERR_TOO_LARGE
+            else:
+                assert 0 < lens[i] < p.size
+                assert O.decode(eh[eoffs[i]:eoffs[i] + lens[i]].tobytes(), guard=64) == p.tobytes()
+    finally:
+        ctx.close()

@@ -126,7 +126,8 @@ def test_batches_over_the_devices(ctx, multi, level):
     parts = []
     for i, n in enumerate(sizes):
         k = i % 3
-        parts.append((synth.text_like(n, seed=20 + i) if k == 0 else synth.json_like(n, seed=30 + i) if k == 1 else
+        parts.append(b"" if n == 0 else
+                     (synth.text_like(n, seed=20 + i) if k == 0 else synth.json_like(n, seed=30 + i) if k == 1 else
                       np.concatenate([synth.text_like(n // 2, seed=40 + i), rng.integers(0, 256, n - n // 2, dtype=np.uint8)])).tobytes())
     one = mz.encode_batch(parts, level, ctx)
     many = mz.encode_batch(parts, level, multi)

@@ -13,6 +13,7 @@ restatement compresses like text of that kind (ratio ~0.47; synth.enwik_like).  
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
     python bench.py --mode stream --workload json --level 2 --bytes B [--gpus N]   # BASELINE config 3: ONE stream written and read by N GPUs
+    python bench.py --gpus N --single-process          # ONE process, one context over N devices (mlz_init_devices): host-to-host rates, the form a Go host binds
     MINLZ_BENCH_ONE_GPU=1 python bench.py --gpus 2 ...  # TEST mode: N ranks, all on cuda:0, over gloo (host-staged) — runs the N > 1
                                                         # code path on a 1-GPU box; the line carries config.TEST_MODE and is no measurement
 
@@ -256,6 +257,95 @@ def stream_mode(args, ctx, mz, synth, dist, dev, rank, world):
         dist.destroy_process_group()
 
 
+def host_path_rates(mz, mctx, host, level, block, reps=4):
+    """Pinned host -> mlz_encode_batch / mlz_decode_batch / mlz_stream_encode / mlz_stream_decode -> pinned host through ONE context (of one
+    device or of several, mlz_init_devices): what a host-language caller of the C ABI sees, PCIe included.  Returns MB/s per direction."""
+    from minlz_amd import _lib
+    L = _lib.lib()
+    vp, sz = C.c_void_p, C.c_size_t
+    S = host.size
+    nblk = (S + block - 1) // block
+    blk_len = [min(block, S - i * block) for i in range(nblk)]
+    psrc = torch.empty(S, dtype=torch.uint8, pin_memory=True); psrc.numpy()[:] = host
+    penc = torch.empty(nblk * (block + 64), dtype=torch.uint8, pin_memory=True); penc.zero_()
+    pdec = torch.empty(S, dtype=torch.uint8, pin_memory=True); pdec.zero_()
+    sp = (vp * nblk)(*[psrc.data_ptr() + i * block for i in range(nblk)]); sl = (sz * nblk)(*blk_len)
+    ep = (vp * nblk)(*[penc.data_ptr() + i * (block + 64) for i in range(nblk)]); ec = (sz * nblk)(*[block + 64] * nblk)
+    ol = (C.c_int64 * nblk)()
+    assert L.mlz_encode_batch(mctx.handle, level, nblk, sp, sl, ep, ec, ol) == 0
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        L.mlz_encode_batch(mctx.handle, level, nblk, sp, sl, ep, ec, ol)
+    te = (time.perf_counter() - t0) / reps
+    cl = (sz * nblk)(*[ol[i] for i in range(nblk)])
+    dp = (vp * nblk)(*[pdec.data_ptr() + i * block for i in range(nblk)]); dc = (sz * nblk)(*blk_len)
+    dl = (C.c_int64 * nblk)()
+    assert L.mlz_decode_batch(mctx.handle, nblk, ep, cl, dp, dc, dl) == 0
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        L.mlz_decode_batch(mctx.handle, nblk, ep, cl, dp, dc, dl)
+    td = (time.perf_counter() - t0) / reps
+    assert bytes(pdec.numpy()) == host.tobytes(), "host-path batch round trip differs"
+    # one framed stream (Writer / Reader in one call each, CRCs included)
+    cap = L.mlz_stream_bound(S, block, 0)
+    pst = torch.empty(cap, dtype=torch.uint8, pin_memory=True); pst.zero_()
+    n = L.mlz_stream_encode(mctx.handle, level, block, 0, psrc.data_ptr(), S, pst.data_ptr(), cap)
+    assert n > 0, n
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        L.mlz_stream_encode(mctx.handle, level, block, 0, psrc.data_ptr(), S, pst.data_ptr(), cap)
+    tse = (time.perf_counter() - t0) / reps
+    pdec.zero_()
+    assert L.mlz_stream_decode(mctx.handle, 0, pst.data_ptr(), n, pdec.data_ptr(), S) == S
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        L.mlz_stream_decode(mctx.handle, 0, pst.data_ptr(), n, pdec.data_ptr(), S)
+    tsd = (time.perf_counter() - t0) / reps
+    assert bytes(pdec.numpy()) == host.tobytes(), "host-path stream round trip differs"
+    mb = S / 1e6
+    return {"encode": round(mb / te, 1), "decode": round(mb / td, 1), "pair": round(mb / (te + td), 1),
+            "stream_encode": round(mb / tse, 1), "stream_decode": round(mb / tsd, 1), "stream_pair": round(mb / (tse + tsd), 1),
+            "bytes": int(S), "blocks": int(nblk), "stream_bytes": int(n)}
+
+
+def single_process_mode(args):
+    """`--gpus N --single-process`: ONE process, one context over N devices (mlz_init_devices) — the form a Go host binds.  Host-to-host
+    rates through the C ABI's host-pointer calls (pinned memory on both sides), N x --bytes of input dealt to the devices by the library;
+    the same stream through one device for comparison.  PCIe-inclusive: each device moves its share over its own link."""
+    import minlz_amd as mz
+    from minlz_amd import synth
+    have = torch.cuda.device_count()
+    one_gpu = bool(os.environ.get("MINLZ_BENCH_ONE_GPU"))
+    if have < args.gpus and not (one_gpu and have >= 1):
+        sys.exit("bench.py --gpus %d --single-process: only %d GPU(s) visible on this box" % (args.gpus, have))
+    devices = [0] * args.gpus if one_gpu else list(range(args.gpus))
+    S = args.bytes * args.gpus
+    gen = {"enwik": lambda: synth.enwik_like(S, seed=1), "text": lambda: synth.text_like(S, seed=1),
+           "json": lambda: synth.json_like(S, seed=77), "random": lambda: synth.random_bytes(S, seed=5)}[args.workload]
+    host = gen()
+    many = mz.Context(devices=devices)
+    one = mz.Context(devices[0])
+    try:
+        for c in (many, one):
+            c.set_option(mz.OPT_ENCODE_FAR, args.far)
+        r_many = host_path_rates(mz, many, host, args.level, BLOCK, reps=max(2, args.steps // 5))
+        r_one = host_path_rates(mz, one, host, args.level, BLOCK, reps=max(2, args.steps // 5))
+        cfg = {"workload": "%s, %d x %d bytes in 8 MiB blocks, ONE process, one context over devices %s (mlz_init_devices); host-pointer calls, pinned memory both sides" %
+                           (args.workload, args.gpus, args.bytes, devices),
+               "devices": devices, "device": many.device_name(), "end_to_end_MBps": r_many, "one_device_same_input_MBps": r_one,
+               "speedup_pair": round(r_many["pair"] / r_one["pair"], 3), "speedup_stream_pair": round(r_many["stream_pair"] / r_one["stream_pair"], 3),
+               "level": args.level}
+        if one_gpu:
+            cfg["TEST_MODE"] = "MINLZ_BENCH_ONE_GPU: every context on cuda:0 — exercises the several-device path, not a scaling measurement"
+        ms = host.size / 1e6 / r_many["pair"] * 1e3
+        print(json.dumps({"metric": "MB/s encode+decode, 8MB blocks L%d, host to host through the C ABI, one process over N MI355X" % args.level,
+                          "value": r_many["pair"], "unit": "MB/s", "n_gpus": args.gpus, "steps": max(2, args.steps // 5), "warmup": 1,
+                          "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8",
+                          "data": "synthetic", "config": cfg}), flush=True)
+    finally:
+        many.close(); one.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -274,7 +364,12 @@ def main():
     ap.add_argument("--strong-bytes", type=int, default=4 << 30,
                     help="N > 1, blocks mode: size of the ONE stream of the config-3 strong-scaling leg reported as config.config3_strong (0 = skip)")
     ap.add_argument("--file", default=os.environ.get("MINLZ_BENCH_FILE"), help="real input (e.g. enwik8); every rank reads its own --bytes slice, wrapping around")
+    ap.add_argument("--single-process", action="store_true",
+                    help="ONE process with one context over --gpus devices (mlz_init_devices), host-pointer calls: the form a Go host binds; prints end_to_end_MBps")
     args = ap.parse_args()
+
+    if args.single_process:
+        return single_process_mode(args)
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # `python bench.py --gpus N` without a launcher: start the N ranks here (one process per GPU, the same command the
@@ -676,6 +771,16 @@ def main():
         extras["end_to_end_MBps"] = {"encode": round(S / 1e6 / te, 1), "decode": round(S / 1e6 / td, 1), "pair": round(S / 1e6 / (te + td), 1),
                                      "note": "pinned host -> mlz_encode_batch / mlz_decode_batch -> pinned host, copies overlapped with kernels in 32 MiB groups"}
         del psrc, penc, pdec
+        # ---- the same through ONE context over two per-device contexts on this GPU (mlz_init_devices {d, d}: the single-process fan-out a Go
+        # host binds; on one GPU the second context overlaps its copies with the first one's kernels, the PCIe link is shared) ----
+        try:
+            two = mz.Context(devices=[local, local])
+            two.set_option(mz.OPT_ENCODE_FAR, args.far)
+            extras["end_to_end_two_contexts_MBps"] = host_path_rates(mz, two, host, args.level, BLOCK, reps=3)
+            extras["end_to_end_two_contexts_MBps"]["note"] = "mlz_init_devices({%d, %d}): one process, two per-device contexts on ONE GPU; `python bench.py --gpus N --single-process` is the N-GPU form" % (local, local)
+            two.close()
+        except Exception as e:  # noqa: BLE001
+            extras["end_to_end_two_contexts_MBps"] = {"error": repr(e)}
         # ---- the round-1 stand-in, for continuity with BENCH_r01 ----
         if args.workload == "enwik" and not args.file and args.level == 1:
             leg = Leg(synth.text_like(S, seed=1))

@@ -46,15 +46,34 @@ var (
 	hipCtx  *C.mlz_ctx
 )
 
-// hipContext returns the process-wide device context, or nil when no device is usable.
+// hipContext returns the process-wide context, or nil when no device is usable.
+//
+// It spans EVERY visible GPU (mlz_init_devices with a nil list; restrict it with HIP_VISIBLE_DEVICES): a Go program is one process,
+// so the fan-out of a stream's blocks over the GPUs of a node lives behind the C ABI — mlz_stream_encode / mlz_stream_decode and the
+// batch calls deal contiguous block ranges to the devices, each over its own PCIe link, and the results land in the caller's buffer at
+// their final offsets (no collective: the consumer is host memory).  Single-block calls (the Writer's goroutine per block,
+// writer.go:501-560; the Reader's, reader.go:830-859) go to the devices in turn, each device with its own combining queue.
+//
+// One context serializes the calls that reach the SAME device (a device owns one workspace): two Writers in one process share the
+// devices' queues.  That is the intended behaviour for a node-wide back end — the queue batches their blocks into common launches —;
+// a program that wants two independent pipelines on one GPU lists the device twice (mlz_init_devices({0, 0}, 2, ...)).
 func hipContext() *C.mlz_ctx {
 	hipOnce.Do(func() {
 		var c *C.mlz_ctx
-		if C.mlz_init(-1, &c) == 0 {
+		if C.mlz_init_devices(nil, 0, &c) == 0 {
 			hipCtx = c
 		}
 	})
 	return hipCtx
+}
+
+// HIPDevices reports how many GPUs the back end deals blocks to (0 = no usable device: every call takes the CPU path).
+func HIPDevices() int {
+	c := hipContext()
+	if c == nil {
+		return 0
+	}
+	return int(C.mlz_device_count(c))
 }
 
 // hipError maps -MLZ_ERR_* (include/minlz_hip.h) to the package's errors.

@@ -163,6 +163,17 @@ int64_t mlz_stream_encode(mlz_ctx* ctx, int level, uint32_t block_size, uint32_t
 int64_t mlz_stream_decoded_len(const uint8_t* src, size_t n); /* host-only chunk walk: total decoded bytes */
 int64_t mlz_stream_decode(mlz_ctx* ctx, uint32_t flags, const uint8_t* src, size_t n, uint8_t* dst, size_t dst_cap);
 
+/* The device-resident Writer over several devices: range j of the stream lies in HBM at d_src[j] (src_len[j] bytes; every range but the last a whole
+ * number of blocks), on any device of the context — normally range j on device j, the concurrent Writer's workers (writer.go:501-560) being the GPUs —
+ * and the framed stream (header, the chunks in order, EOF, index with MLZ_STREAM_ADD_INDEX) is assembled in d_dst, a buffer on ONE device.  Every device
+ * encodes and checksums its range and frames its run of chunks in its own HBM; 12 bytes per block (size, CRC) visit the host, so that every run's place
+ * is known (the in-order emit, writer.go:219-272); the runs then travel GPU to GPU into d_dst (hipMemcpyPeerAsync: xGMI between the GPUs of a node; a run
+ * already on d_dst's device is framed in place).  No payload crosses PCIe and there is no collective: a gather of variable-length runs to one consumer
+ * is n - 1 point-to-point copies, which is also all RCCL's gather would issue.  Bytes are identical to mlz_stream_encode of the concatenated ranges.
+ * Synchronous; returns the stream size.  Works on a one-device context too (n_ranges ranges encoded one after the other). */
+int64_t mlz_stream_encode_gather_device(mlz_ctx* ctx, int level, uint32_t block_size, uint32_t flags, const uint8_t* const* d_src, const size_t* src_len,
+                                        int n_ranges, uint8_t* d_dst, size_t dst_cap);
+
 /* ---- tuning / introspection (not part of the reference surface) ---- */
 #define MLZ_OPT_DECODE_ALGO 1  /* 0 = parallel (default), 1 = serial one-wave-per-block, 3 = parallel with every block on the tile path (cross-checks) */
 #define MLZ_OPT_ENCODE_FAR 2   /* 0 = tile-local matches only, 1 = + far matches (default) */

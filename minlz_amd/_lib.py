@@ -16,6 +16,7 @@ SYMBOLS = [
     "mlz_decode_batch", "mlz_encode_batch_device", "mlz_decode_batch_device", "mlz_set_option", "mlz_get_timers",
     "mlz_timer_name", "mlz_crc", "mlz_crc_batch_device", "mlz_stream_bound", "mlz_stream_encode", "mlz_stream_decoded_len",
     "mlz_stream_decode", "mlz_get_counter", "mlz_init_devices", "mlz_device_count", "mlz_device_ctx",
+    "mlz_stream_encode_gather_device",
 ]
 
 
@@ -64,6 +65,8 @@ def lib():
     L.mlz_stream_bound.argtypes = [u64, u32, u32]; L.mlz_stream_bound.restype = i64
     L.mlz_stream_encode.argtypes = [vp, i32, u32, u32, vp, sz, vp, sz]; L.mlz_stream_encode.restype = i64
     L.mlz_stream_decoded_len.argtypes = [vp, sz]; L.mlz_stream_decoded_len.restype = i64
+    L.mlz_stream_encode_gather_device.argtypes = [vp, i32, u32, u32, C.POINTER(vp), C.POINTER(sz), i32, vp, sz]
+    L.mlz_stream_encode_gather_device.restype = i64
     L.mlz_stream_decode.argtypes = [vp, u32, vp, sz, vp, sz]; L.mlz_stream_decode.restype = i64
     _lib = L
     return L

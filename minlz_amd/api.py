@@ -124,6 +124,16 @@ class Context:
         """Workgroups per block (1, 2 or 4) the general-block pass of the last decode call settled with; 0 = no general block (mlz_get_counter 6)."""
         return int(_lib.lib().mlz_get_counter(self.handle, 6))
 
+    def stream_encode_gather_device(self, level, block_size, add_index, d_srcs, lens, d_dst, dst_cap):
+        """mlz_stream_encode_gather_device: ranges of one stream resident on the context's devices -> the framed stream in d_dst (device memory).
+        Returns the stream size."""
+        n = len(d_srcs)
+        sp = (C.c_void_p * n)(*d_srcs); sl = (C.c_size_t * n)(*lens)
+        r = _lib.lib().mlz_stream_encode_gather_device(self.handle, level, block_size, STREAM_ADD_INDEX if add_index else 0, sp, sl, n, d_dst, dst_cap)
+        if r < 0:
+            _raise(r, self)
+        return int(r)
+
     # ---- device-resident batch calls: pointers are raw device addresses (e.g. tensor.data_ptr()) ----
     def encode_batch_device(self, stream, level, d_src, d_dst, descs, d_out_len):
         arr = (BlockDesc * len(descs))(*descs) if not isinstance(descs, C.Array) else descs

@@ -199,3 +199,45 @@ def test_device_resident_calls_find_their_device(multi):
     host = np.zeros(64, dtype=np.uint8)
     with pytest.raises(mz.MinLZError):
         multi.encode_batch_device(0, 1, host.ctypes.data, host.ctypes.data, [BlockDesc(0, 16, 0, 18)], host.ctypes.data)
+
+
+@pytest.mark.parametrize("level,bs,add_index", [(1, 1 << 20, True), (2, 4 << 20, False), (1, 8 << 20, True)])
+def test_device_resident_gather_is_the_host_streams_twin(ctx, multi, level, bs, add_index):
+    """mlz_stream_encode_gather_device: ranges of one stream in the devices' HBM, the framed stream assembled on ONE device GPU to GPU — the same
+    bytes as mlz_stream_encode of the concatenation (and so decodable by the reference Reader's restatement)."""
+    import torch
+    L = _lib.lib()
+    ndev = torch.cuda.device_count()
+    k = multi.device_count()
+    devs = [0] * k if ndev < 2 else [i % ndev for i in range(k)]
+    # whole blocks per range, the last one ragged; an incompressible stretch (stored chunks come from the raw source, not the encoder's output)
+    parts = [synth.text_like(3 * bs, seed=5).tobytes(), (synth.random_bytes(bs, seed=6).tobytes() + synth.json_like(bs, seed=7).tobytes()),
+             synth.json_like(2 * bs + 12345, seed=8).tobytes()][:max(2, min(3, k))]
+    if len(parts) == 2:
+        parts[1] = parts[1] + synth.json_like(bs // 2 + 1, seed=8).tobytes()
+    whole = b"".join(parts)
+    want = mz.stream_encode(whole, level, bs, add_index, ctx)
+    srcs = []
+    for j, p in enumerate(parts):
+        with torch.cuda.device(devs[j % len(devs)]):
+            srcs.append(torch.from_numpy(np.frombuffer(p, dtype=np.uint8).copy()).cuda())
+    cap = L.mlz_stream_bound(len(whole), bs, 1 if add_index else 0)
+    with torch.cuda.device(0):
+        dst = torch.full((cap + 64,), 0x5A, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    n = multi.stream_encode_gather_device(level, bs, add_index, [t.data_ptr() for t in srcs], [t.numel() for t in srcs], dst.data_ptr(), cap)
+    got = dst.cpu().numpy()
+    assert n == len(want) and got[:n].tobytes() == want
+    assert (got[cap:] == 0x5A).all()
+    assert O.stream_decode(want, len(whole)) == whole
+    # a one-device context takes the ranges one after the other: same bytes
+    n1 = ctx.stream_encode_gather_device(level, bs, add_index, [t.data_ptr() for t in srcs if t.device.index == 0][:1] or [srcs[0].data_ptr()],
+                                         [parts and srcs[0].numel()], dst.data_ptr(), cap)
+    assert dst.cpu().numpy()[:n1].tobytes() == mz.stream_encode(parts[0], level, bs, add_index, ctx)
+    # argument checks: a ragged range in the middle, a host pointer
+    if len(srcs) >= 2:
+        with pytest.raises(mz.MinLZError):
+            multi.stream_encode_gather_device(level, bs, add_index, [srcs[0].data_ptr(), srcs[1].data_ptr()], [srcs[0].numel() - 1, srcs[1].numel()], dst.data_ptr(), cap)
+    host = np.zeros(bs, dtype=np.uint8)
+    with pytest.raises(mz.MinLZError):
+        multi.stream_encode_gather_device(level, bs, add_index, [host.ctypes.data], [host.size], dst.data_ptr(), cap)

@@ -257,9 +257,10 @@ def stream_mode(args, ctx, mz, synth, dist, dev, rank, world):
         dist.destroy_process_group()
 
 
-def host_path_rates(mz, mctx, host, level, block, reps=4):
+def host_path_rates(mz, mctx, host, level, block, reps=5):
     """Pinned host -> mlz_encode_batch / mlz_decode_batch / mlz_stream_encode / mlz_stream_decode -> pinned host through ONE context (of one
-    device or of several, mlz_init_devices): what a host-language caller of the C ABI sees, PCIe included.  Returns MB/s per direction."""
+    device or of several, mlz_init_devices): what a host-language caller of the C ABI sees, PCIe included.  Returns MB/s per direction
+    (the median call of `reps`: a call now and then takes twice as long on the host side — page-locked first touches, thread wake-ups)."""
     from minlz_amd import _lib
     L = _lib.lib()
     vp, sz = C.c_void_p, C.c_size_t
@@ -272,40 +273,37 @@ def host_path_rates(mz, mctx, host, level, block, reps=4):
     sp = (vp * nblk)(*[psrc.data_ptr() + i * block for i in range(nblk)]); sl = (sz * nblk)(*blk_len)
     ep = (vp * nblk)(*[penc.data_ptr() + i * (block + 64) for i in range(nblk)]); ec = (sz * nblk)(*[block + 64] * nblk)
     ol = (C.c_int64 * nblk)()
+
+    def med(fn):
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            fn()
+            ts.append(time.perf_counter() - t0)
+        return sorted(ts)[len(ts) // 2]
+
     assert L.mlz_encode_batch(mctx.handle, level, nblk, sp, sl, ep, ec, ol) == 0
-    t0 = time.perf_counter()
-    for _ in range(reps):
-        L.mlz_encode_batch(mctx.handle, level, nblk, sp, sl, ep, ec, ol)
-    te = (time.perf_counter() - t0) / reps
+    te = med(lambda: L.mlz_encode_batch(mctx.handle, level, nblk, sp, sl, ep, ec, ol))
     cl = (sz * nblk)(*[ol[i] for i in range(nblk)])
     dp = (vp * nblk)(*[pdec.data_ptr() + i * block for i in range(nblk)]); dc = (sz * nblk)(*blk_len)
     dl = (C.c_int64 * nblk)()
     assert L.mlz_decode_batch(mctx.handle, nblk, ep, cl, dp, dc, dl) == 0
-    t0 = time.perf_counter()
-    for _ in range(reps):
-        L.mlz_decode_batch(mctx.handle, nblk, ep, cl, dp, dc, dl)
-    td = (time.perf_counter() - t0) / reps
+    td = med(lambda: L.mlz_decode_batch(mctx.handle, nblk, ep, cl, dp, dc, dl))
     assert bytes(pdec.numpy()) == host.tobytes(), "host-path batch round trip differs"
     # one framed stream (Writer / Reader in one call each, CRCs included)
     cap = L.mlz_stream_bound(S, block, 0)
     pst = torch.empty(cap, dtype=torch.uint8, pin_memory=True); pst.zero_()
     n = L.mlz_stream_encode(mctx.handle, level, block, 0, psrc.data_ptr(), S, pst.data_ptr(), cap)
     assert n > 0, n
-    t0 = time.perf_counter()
-    for _ in range(reps):
-        L.mlz_stream_encode(mctx.handle, level, block, 0, psrc.data_ptr(), S, pst.data_ptr(), cap)
-    tse = (time.perf_counter() - t0) / reps
+    tse = med(lambda: L.mlz_stream_encode(mctx.handle, level, block, 0, psrc.data_ptr(), S, pst.data_ptr(), cap))
     pdec.zero_()
     assert L.mlz_stream_decode(mctx.handle, 0, pst.data_ptr(), n, pdec.data_ptr(), S) == S
-    t0 = time.perf_counter()
-    for _ in range(reps):
-        L.mlz_stream_decode(mctx.handle, 0, pst.data_ptr(), n, pdec.data_ptr(), S)
-    tsd = (time.perf_counter() - t0) / reps
+    tsd = med(lambda: L.mlz_stream_decode(mctx.handle, 0, pst.data_ptr(), n, pdec.data_ptr(), S))
     assert bytes(pdec.numpy()) == host.tobytes(), "host-path stream round trip differs"
     mb = S / 1e6
     return {"encode": round(mb / te, 1), "decode": round(mb / td, 1), "pair": round(mb / (te + td), 1),
             "stream_encode": round(mb / tse, 1), "stream_decode": round(mb / tsd, 1), "stream_pair": round(mb / (tse + tsd), 1),
-            "bytes": int(S), "blocks": int(nblk), "stream_bytes": int(n)}
+            "bytes": int(S), "blocks": int(nblk), "stream_bytes": int(n), "calls_timed": reps}
 
 
 def single_process_mode(args):
@@ -328,8 +326,8 @@ def single_process_mode(args):
     try:
         for c in (many, one):
             c.set_option(mz.OPT_ENCODE_FAR, args.far)
-        r_many = host_path_rates(mz, many, host, args.level, BLOCK, reps=max(2, args.steps // 5))
-        r_one = host_path_rates(mz, one, host, args.level, BLOCK, reps=max(2, args.steps // 5))
+        r_many = host_path_rates(mz, many, host, args.level, BLOCK, reps=max(3, args.steps // 4))
+        r_one = host_path_rates(mz, one, host, args.level, BLOCK, reps=max(3, args.steps // 4))
         cfg = {"workload": "%s, %d x %d bytes in 8 MiB blocks, ONE process, one context over devices %s (mlz_init_devices); host-pointer calls, pinned memory both sides" %
                            (args.workload, args.gpus, args.bytes, devices),
                "devices": devices, "device": many.device_name(), "end_to_end_MBps": r_many, "one_device_same_input_MBps": r_one,
@@ -339,7 +337,7 @@ def single_process_mode(args):
             cfg["TEST_MODE"] = "MINLZ_BENCH_ONE_GPU: every context on cuda:0 — exercises the several-device path, not a scaling measurement"
         ms = host.size / 1e6 / r_many["pair"] * 1e3
         print(json.dumps({"metric": "MB/s encode+decode, 8MB blocks L%d, host to host through the C ABI, one process over N MI355X" % args.level,
-                          "value": r_many["pair"], "unit": "MB/s", "n_gpus": args.gpus, "steps": max(2, args.steps // 5), "warmup": 1,
+                          "value": r_many["pair"], "unit": "MB/s", "n_gpus": args.gpus, "steps": max(3, args.steps // 4), "warmup": 1,
                           "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8",
                           "data": "synthetic", "config": cfg}), flush=True)
     finally:

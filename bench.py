@@ -134,13 +134,32 @@ def stream_leg(ctx, mz, synth, dist, dev, rank, world, total, level, workload, s
     lo, hi = min(b0 * BLOCK, total), min(b1 * BLOCK, total)
     gen = {"enwik": synth.enwik_like, "text": synth.text_like, "json": synth.json_like, "random": synth.random_bytes}[workload]
     span = hi - lo
-    if tile_from and span > tile_from:
-        base = torch.from_numpy(gen(tile_from, seed=100 + rank)).to(dev)
-        src = base.repeat((span + tile_from - 1) // tile_from)[:span].contiguous()
-        del base
-    else:
-        src = torch.from_numpy(gen(max(span, 1), seed=100 + rank)[:span]).to(dev)     # every rank generates only its own range
-    codec = shard.HipTensorCodec(ctx)
+    # Everything that can fail on ONE rank alone (its range's memory, the encoder's workspace for it) happens before the first collective, inside a
+    # try, and the ranks then AGREE on having got through: a rank that failed while the others went on into all_gather / barrier would hang the
+    # whole job instead of reporting (round-5 advisor finding).
+    problem = None
+    src = codec = None
+    try:
+        if tile_from and span > tile_from:
+            base = torch.from_numpy(gen(tile_from, seed=100 + rank)).to(dev)
+            src = base.repeat((span + tile_from - 1) // tile_from)[:span].contiguous()
+            del base
+        else:
+            src = torch.from_numpy(gen(max(span, 1), seed=100 + rank)[:span]).to(dev)     # every rank generates only its own range
+        codec = shard.HipTensorCodec(ctx)
+        if dist is not None and span > 0:      # a local dry run of the rank's own encode (no collective inside): buffers and workspace at their full size
+            lens = [min(BLOCK, span - o) for o in range(0, span, BLOCK)]
+            codec.encode(src, lens, level)
+            torch.cuda.synchronize(dev)
+    except Exception as ex:  # noqa: BLE001
+        problem = "%s: %s" % (type(ex).__name__, str(ex)[:200])
+    if dist is not None:
+        okt = torch.tensor([0 if problem else 1], dtype=torch.int32, device="cpu" if dist.get_backend() == "gloo" else dev)
+        dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+        if int(okt.item()) == 0:
+            raise RuntimeError("stream leg not run: a rank failed in its local set-up (%s)" % (problem or "another rank"))
+    elif problem:
+        raise RuntimeError(problem)
 
     def step():
         return shard.encode_stream_sharded_device(codec, src, total, BLOCK, level, rank, world)

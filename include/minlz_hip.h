@@ -129,6 +129,10 @@ int mlz_decode_batch(mlz_ctx* ctx, int n_blocks, const uint8_t* const* src, cons
  * per output byte on text-like data, 5.3 GB for a full group.  Encode holds about 3.3 bytes per input byte (token records, piece
  * scratch) plus the far tables (1.5 MiB per 8 MiB block, LevelBalanced 8 MiB): about 3 GB per group.  If the general pass's buffers
  * cannot be allocated, general blocks decode on the exec pass's tile chain instead (slow, correct; mlz_get_counter 5 counts such calls). */
+/* A stream that was used for a *_batch_device call and is about to be destroyed: call this first (any time after the last call on it).  The context
+ * then records its ordering event on the stream while it is alive; without it the event is recorded lazily, by the context's NEXT call, on the previous
+ * call's stream — which must therefore still exist then.  Not needed for streams that outlive the context's use, nor for the host-pointer calls. */
+int mlz_release_stream(mlz_ctx* ctx, void* stream);
 int mlz_encode_batch_device(mlz_ctx* ctx, void* stream, int level, const uint8_t* d_src, uint8_t* d_dst,
                             const mlz_block_desc* desc, int n_blocks, int64_t* d_out_len);
 int mlz_decode_batch_device(mlz_ctx* ctx, void* stream, const uint8_t* d_src, uint8_t* d_dst,

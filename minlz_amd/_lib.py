@@ -16,7 +16,7 @@ SYMBOLS = [
     "mlz_decode_batch", "mlz_encode_batch_device", "mlz_decode_batch_device", "mlz_set_option", "mlz_get_timers",
     "mlz_timer_name", "mlz_crc", "mlz_crc_batch_device", "mlz_stream_bound", "mlz_stream_encode", "mlz_stream_decoded_len",
     "mlz_stream_decode", "mlz_get_counter", "mlz_init_devices", "mlz_device_count", "mlz_device_ctx",
-    "mlz_stream_encode_gather_device",
+    "mlz_stream_encode_gather_device", "mlz_release_stream",
 ]
 
 
@@ -56,6 +56,7 @@ def lib():
     L.mlz_encode_batch_device.argtypes = [vp, vp, i32, vp, vp, C.POINTER(BlockDesc), i32, vp]; L.mlz_encode_batch_device.restype = i32
     L.mlz_decode_batch_device.argtypes = [vp, vp, vp, vp, C.POINTER(BlockDesc), i32, vp]; L.mlz_decode_batch_device.restype = i32
     L.mlz_set_option.argtypes = [vp, i32, i64]; L.mlz_set_option.restype = i32
+    L.mlz_release_stream.argtypes = [vp, vp]; L.mlz_release_stream.restype = i32
     L.mlz_get_timers.argtypes = [vp, C.POINTER(C.c_float), i32]; L.mlz_get_timers.restype = i32
     L.mlz_timer_name.argtypes = [i32]; L.mlz_timer_name.restype = C.c_char_p
     L.mlz_get_counter.argtypes = [vp, i32]; L.mlz_get_counter.restype = i64

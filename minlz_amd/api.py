@@ -124,6 +124,12 @@ class Context:
         """Workgroups per block (1, 2 or 4) the general-block pass of the last decode call settled with; 0 = no general block (mlz_get_counter 6)."""
         return int(_lib.lib().mlz_get_counter(self.handle, 6))
 
+    def release_stream(self, stream):
+        """mlz_release_stream: call before destroying a stream that carried a *_batch_device call of this context."""
+        r = _lib.lib().mlz_release_stream(self.handle, stream)
+        if r:
+            _raise(r, self)
+
     def stream_encode_gather_device(self, level, block_size, add_index, d_srcs, lens, d_dst, dst_cap):
         """mlz_stream_encode_gather_device: ranges of one stream resident on the context's devices -> the framed stream in d_dst (device memory).
         Returns the stream size."""

@@ -122,6 +122,7 @@ struct mlz_ctx {
     hipEvent_t ws_done = nullptr;
     hipStream_t ws_stream = nullptr;
     bool ws_used = false;
+    bool ws_recorded = false;   // mlz_release_stream: ws_done already covers the last call (its stream may be gone by the next one)
     // encode workspace
     DevBuf d_scratch, d_tile_size, d_tile_out, d_flags, d_far, d_recs, d_piece_cnt, d_farbin;
     bool farbin_attr = false;
@@ -213,14 +214,16 @@ struct Timer {
 struct WorkspaceOrder {
     mlz_ctx* c; hipStream_t s;
     WorkspaceOrder(mlz_ctx* c_, hipStream_t s_) : c(c_), s(s_) {
-        if (c->ws_used && c->ws_stream != s) {
-            if (hipEventRecord(c->ws_done, c->ws_stream) == hipSuccess) (void)hipStreamWaitEvent(s, c->ws_done, 0);
+        if (c->ws_used && (c->ws_recorded || c->ws_stream != s)) {
+            if (c->ws_recorded) (void)hipStreamWaitEvent(s, c->ws_done, 0);   // recorded by mlz_release_stream while the stream was alive
+            else if (hipEventRecord(c->ws_done, c->ws_stream) == hipSuccess) (void)hipStreamWaitEvent(s, c->ws_done, 0);
             else { (void)hipGetLastError(); (void)hipDeviceSynchronize(); }   // (the caller destroyed that stream: whatever it held is waited for)
         }
     }
     ~WorkspaceOrder() {
         c->ws_stream = s;
         c->ws_used = true;
+        c->ws_recorded = false;
     }
 };
 
@@ -1137,6 +1140,21 @@ int mlz_set_option(mlz_ctx* c, int opt, int64_t value) {
         return 0;
     default: return -MLZ_ERR_ARG;
     }
+}
+
+int mlz_release_stream(mlz_ctx* c, void* stream) {
+    if (!c) return -MLZ_ERR_ARG;
+    if (!c->kids.empty()) {
+        for (mlz_ctx* k : c->kids) { const int r = mlz_release_stream(k, stream); if (r) return r; }
+        return 0;
+    }
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (c->ws_used && !c->ws_recorded && c->ws_stream == static_cast<hipStream_t>(stream)) {
+        HIPCHK(c, hipSetDevice(c->device));
+        HIPCHK(c, hipEventRecord(c->ws_done, c->ws_stream));   // covers everything the context put on that stream
+        c->ws_recorded = true;
+    }
+    return 0;
 }
 
 int64_t mlz_get_counter(mlz_ctx* c, int which) {

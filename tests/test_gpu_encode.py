@@ -389,6 +389,46 @@ def test_device_calls_on_two_streams_share_the_workspace(ctx):
     assert out_a == a.tobytes() and out_b == b_.tobytes()
 
 
+def test_a_stream_destroyed_between_calls(ctx):
+    # mlz_release_stream: a stream that carried a device call is released and DESTROYED before the context's next call on another stream —
+    # the context's ordering event was recorded while the stream was alive, so the next call neither touches the dead handle nor runs
+    # ahead of the first call's kernels (round-5 advisor finding: the lazy record on a destroyed stream was undefined behaviour).
+    import ctypes as C
+    import torch
+    from minlz_amd._lib import BlockDesc
+    # the HIP runtime this process already runs on (PyTorch bundles its own copy: a second one would not know the library's context)
+    path = next(l.split()[-1] for l in open("/proc/self/maps") if "libamdhip64" in l)
+    hip = C.CDLL(path)
+    hip.hipStreamCreate.argtypes = [C.POINTER(C.c_void_p)]
+    hip.hipStreamDestroy.argtypes = [C.c_void_p]
+    dev = torch.device("cuda", 0)
+    a = synth.text_like(16 << 20, 61)
+    b_ = synth.json_like(8 << 20, 62)
+    A, B = torch.from_numpy(a).to(dev), torch.from_numpy(b_).to(dev)
+    blk = 8 << 20
+    stride = blk + 256
+    def desc(n):
+        k = (n + blk - 1) // blk
+        return (BlockDesc * k)(*[BlockDesc(i * blk, min(blk, n - i * blk), i * stride, stride) for i in range(k)]), k
+    da, ka = desc(a.size)
+    db, kb = desc(b_.size)
+    ea = torch.zeros(ka * stride, dtype=torch.uint8, device=dev); la = torch.zeros(ka, dtype=torch.int64, device=dev)
+    eb = torch.zeros(kb * stride, dtype=torch.uint8, device=dev); lb = torch.zeros(kb, dtype=torch.int64, device=dev)
+    torch.cuda.synchronize()
+    s2 = torch.cuda.Stream(dev)
+    for _ in range(3):
+        h = C.c_void_p()
+        assert hip.hipStreamCreate(C.byref(h)) == 0
+        ctx.encode_batch_device(h, 1, A.data_ptr(), ea.data_ptr(), da, la.data_ptr())
+        ctx.release_stream(h)
+        assert hip.hipStreamDestroy(h) == 0        # (waits for the stream's work or not: the library does not care any more)
+        ctx.encode_batch_device(s2.cuda_stream, 1, B.data_ptr(), eb.data_ptr(), db, lb.data_ptr())
+    torch.cuda.synchronize()
+    ha, hb = ea.cpu().numpy(), eb.cpu().numpy()
+    assert b"".join(O.decode(ha[i * stride:i * stride + l].tobytes()) for i, l in enumerate(la.cpu().tolist())) == a.tobytes()
+    assert b"".join(O.decode(hb[i * stride:i * stride + l].tobytes()) for i, l in enumerate(lb.cpu().tolist())) == b_.tobytes()
+
+
 def test_host_batch_pinned_destinations(ctx):
     # Host-pointer batch calls with page-locked buffers: the kernels write the caller's buffers themselves (no copy-out
     # stage).  Every kind of block goes through it — tokens, stored, tiny, empty, and (decode) streams of the

@@ -140,6 +140,7 @@ struct mlz_ctx {
     int l2_free = 1;           // option 14 (default on): LevelBalanced without the tile-level constraint (better ratio; its blocks decode through the general path)
     uint64_t gen_fallbacks = 0;  // decode calls whose general blocks took the tile chain because the general pass's buffers could not be allocated (mlz_get_counter 5)
     int gen_force_packed = 0;  // tests: every tile of a general block takes the byte-packed pool (the fallback path)
+    int fuse_ser = 1;          // option 21: the match kernel serializes its pieces itself (0: serialize_pieces_kernel, rounds 2-5; cross-checks)
     // host-pointer staging
     DevBuf d_in, d_out, d_len, d_crc, d_crc_tabs, d_crc_tiles;
     // stream calls: copy-in / copy-out streams, event pool, pinned result buffer
@@ -402,27 +403,29 @@ int encode_device_group(mlz_ctx* c, hipStream_t st, int level, const uint8_t* d_
         {
             HIPCHK(c, c->d_recs.ensure(units * kRecPerPiece * sizeof(uint2)));
             HIPCHK(c, c->d_piece_cnt.ensure(units * sizeof(uint32_t)));
+            // the match kernel's waves serialize their pieces themselves (option 21, default on); else serialize_pieces_kernel below
+            uint8_t* fuse_scratch = MLZ_M2_FUSE_SER && c->fuse_ser ? c->d_scratch.as<uint8_t>() : nullptr;
             {
                 Timer t(c, T_ENC_TILES, st);
                 const uint32_t grid = ((tiles + 7) / 8) * 8;  // whole rounds of the eight XCDs (see the kernel's workgroup -> tile map)
 #define MLZ_LAUNCH_M2(F, HB, CLS, ...)                                                                                                       \
     hipLaunchKernelGGL((match_tiles_kernel<F, MLZ_M2_NW, HB, ##__VA_ARGS__>), dim3(grid), dim3(256), M2Cfg<HB>::kLds, st, d_src, blocks, tile_block,        \
-                       c->d_recs.as<uint2>(), c->d_piece_cnt.as<uint32_t>(), ftab, epochs, pattern, tiles, uint32_t(CLS), uint32_t(fbits), far_gap)
+                       c->d_recs.as<uint2>(), c->d_piece_cnt.as<uint32_t>(), ftab, epochs, pattern, tiles, uint32_t(CLS), uint32_t(fbits), far_gap, fuse_scratch, c->d_tile_size.as<uint32_t>())
                 if (level == MLZ_LEVEL_SUPERFAST) MLZ_LAUNCH_M2(false, kM2HashBitsSuperFast, 2);
                 else if (l2new && far) {
                     // the same kernel for both block classes, with far tables of the level's size or of the block's
                     if (any_big)
                         hipLaunchKernelGGL((match_tiles_kernel<true, MLZ_M2_NW, kM2HashBitsSmall, kL2FarBits, true>), dim3(grid), dim3(256), M2Cfg<kM2HashBitsSmall>::kLds,
                                            st, d_src, blocks, tile_block, c->d_recs.as<uint2>(), c->d_piece_cnt.as<uint32_t>(), ftab, epochs, pattern, tiles,
-                                           any_small ? 1u : 2u, uint32_t(fbits), far_gap);
+                                           any_small ? 1u : 2u, uint32_t(fbits), far_gap, fuse_scratch, c->d_tile_size.as<uint32_t>());
                     if (any_small)
                         hipLaunchKernelGGL((match_tiles_kernel<true, MLZ_M2_NW, kM2HashBitsSmall, 0, true>), dim3(grid), dim3(256), M2Cfg<kM2HashBitsSmall>::kLds, st,
                                            d_src, blocks, tile_block, c->d_recs.as<uint2>(), c->d_piece_cnt.as<uint32_t>(), ftab, epochs, pattern, tiles,
-                                           any_big ? 0u : 2u, uint32_t(fbits), far_gap);
+                                           any_big ? 0u : 2u, uint32_t(fbits), far_gap, fuse_scratch, c->d_tile_size.as<uint32_t>());
                 }
                 else if (l2new)   // blocks of one tile: no far tables, but the same near-table seeding as the level's other blocks
                     hipLaunchKernelGGL((match_tiles_kernel<false, MLZ_M2_NW, kM2HashBitsSmall, kL2FarBits, true>), dim3(grid), dim3(256), M2Cfg<kM2HashBitsSmall>::kLds, st,
-                                       d_src, blocks, tile_block, c->d_recs.as<uint2>(), c->d_piece_cnt.as<uint32_t>(), ftab, epochs, pattern, tiles, 2u, uint32_t(fbits), far_gap);
+                                       d_src, blocks, tile_block, c->d_recs.as<uint2>(), c->d_piece_cnt.as<uint32_t>(), ftab, epochs, pattern, tiles, 2u, uint32_t(fbits), far_gap, fuse_scratch, c->d_tile_size.as<uint32_t>());
                 else {
                     // one launch per block class that occurs in the batch (usually one)
                     if (any_big) { if (far) MLZ_LAUNCH_M2(true, kM2HashBitsBig, any_small ? 1 : 2); else MLZ_LAUNCH_M2(false, kM2HashBitsBig, any_small ? 1 : 2); }
@@ -430,7 +433,7 @@ int encode_device_group(mlz_ctx* c, hipStream_t st, int level, const uint8_t* d_
                 }
 #undef MLZ_LAUNCH_M2
             }
-            {
+            if (!fuse_scratch) {
                 Timer t(c, T_ENC_SER, st);
                 hipLaunchKernelGGL(serialize_pieces_kernel, dim3(tiles), dim3(256), kSerLds, st, d_src, blocks, tile_block, c->d_recs.as<uint2>(),
                                    c->d_piece_cnt.as<uint32_t>(), c->d_scratch.as<uint8_t>(), c->d_tile_size.as<uint32_t>());
@@ -1103,6 +1106,7 @@ int mlz_set_option(mlz_ctx* c, int opt, int64_t value) {
     case MLZ_OPT_DEVICE_GROUP: c->device_group = size_t(value > 0 ? value : 1) << 20; return 0;  // MiB of uncompressed data per internal group of a device batch
     case 18: c->far_slices_l2 = int(value); return 0;  // debug / cross-check: LevelBalanced's far tables by the slice kernel of round 4
     case MLZ_OPT_L2_GAP: if (value < 1 || value > 16) return -MLZ_ERR_ARG; c->l2_gap = int(value); return 0;
+    case 21: c->fuse_ser = int(value); return 0;  // encode: 1 (default) = the match kernel serializes its pieces itself, 0 = the separate serializer kernel of rounds 2-5 (cross-checks)
     case 20: c->gen_settle_cap = int(value); return 0;  // tuning: role S workgroups of the general pass at most
     case 14: c->l2_free = int(value); return 0;  // LevelBalanced: 1 = no tile levels (ratio of the reference's L2 and better; blocks decode as general blocks)
     case 13: c->gen_force_packed = int(value); return 0;  // tests: general blocks settle through the byte-packed pool (fallback path of dec_general_kernel)

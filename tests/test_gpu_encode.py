@@ -491,3 +491,24 @@ def test_host_batch_pinned_destinations(ctx):
         keep[o:o + p.size] = False
     assert (dh[keep] == 0x5A).all()
     assert ctx.general_blocks() == 5      # the two reference-algorithm blocks, and this library's three LevelBalanced blocks of more than two tiles (no tile levels: MLZ_OPT_L2_FREE)
+
+
+@pytest.mark.parametrize("level", [-1, 1, 2])
+def test_fused_serializer_writes_the_same_bytes(level):
+    # Round 6: the wave that matched a piece serializes it too (serialize_piece at the end of match_tiles_kernel: literals and the bytes in
+    # front of a match from the tile's LDS copy, the ring in the wave's own near table — 2 KiB for wave 0 of the 12-bit class).  Option 21 = 0
+    # runs the separate serializer kernel of rounds 2-5 on the same records: byte-identical blocks, every block class, ragged ends, long literal runs.
+    rng = np.random.default_rng(9)
+    parts = [synth.enwik_like(8 << 20, 3), synth.json_like((3 << 20) + 77, 4), synth.text_like(700_001, 5), synth.text_like(40_000, 6), synth.text_like(33, 7),
+             np.concatenate([synth.text_like(300_000, 8), rng.integers(0, 256, 900_000, dtype=np.uint8), synth.json_like(500_000, 9)]),   # long literal runs inside a block
+             synth.pattern("zeros", 2_000_001), synth.random_bytes(1 << 20, seed=2), synth.text_like(65_536 + 9, 10), synth.text_like(5, 11)]
+    a, b_ = mz.Context(0), mz.Context(0)
+    try:
+        b_.set_option(21, 0)
+        fused = mz.encode_batch([p.tobytes() for p in parts], level, a)
+        apart = mz.encode_batch([p.tobytes() for p in parts], level, b_)
+        assert fused == apart
+        for blk, p in zip(fused, parts):
+            assert O.decode(blk, guard=64) == p.tobytes()
+    finally:
+        a.close(); b_.close()

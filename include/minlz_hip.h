@@ -68,8 +68,10 @@ void mlz_destroy(mlz_ctx* ctx);
  *   mlz_encode_batch / mlz_decode_batch   deal contiguous block ranges of about equal bytes to the devices, one host thread and one PCIe link per
  *                                          device; every result lands at the caller's dst[i] (page-locked destinations are written by the kernels of
  *                                          whichever device ran the block), so there is nothing to gather and no collective;
- *   mlz_stream_encode                      deals contiguous block ranges the same way; a range's chunks go to their final place in dst once the sizes
- *                                          of the ranges before it are known (the in-order emit); the stream is byte-identical to the one-device call's;
+ *   mlz_stream_encode                      deals the stream's 64 MiB groups of blocks to the devices in turn (group g to device g mod n); a group's chunks go
+ *                                          to their final place in dst as soon as the sizes of the groups before it are known (the in-order emit: they
+ *                                          belong to the same pipeline step of the other devices), under the kernels of the device's next group;
+ *                                          the stream is byte-identical to the one-device call's;
  *   mlz_stream_decode                      deals contiguous chunk ranges of about equal output (every chunk's output offset is known from the chunk walk);
  *   mlz_encode / mlz_decode / *_block / mlz_crc   go to the devices in turn, each with its own combining queue;
  *   the *_batch_device calls               run on the device that holds d_src (-MLZ_ERR_ARG if none of the context's devices does);

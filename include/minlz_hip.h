@@ -44,7 +44,7 @@ extern "C" {
 #define MLZ_ERR_HIP 7           /* HIP runtime failure: caller should fall back to its CPU path */
 #define MLZ_ERR_ARG 8           /* bad argument */
 
-typedef struct mlz_ctx mlz_ctx; /* one per (process, device); thread-safe */
+typedef struct mlz_ctx mlz_ctx; /* one per (process, device) from mlz_init, or one over several devices from mlz_init_devices; thread-safe */
 
 /* One block of a batch.  Offsets are relative to the base pointers passed with the batch. */
 typedef struct {

@@ -883,7 +883,8 @@ int multi_host_batch(mlz_ctx* c, bool encode, int level, int n, const uint8_t* c
     for (size_t j = 1; j < k; j++) th.emplace_back(work, j);
     work(0);
     for (std::thread& t : th) t.join();
-    for (size_t j = 0; j < k; j++) if (rcs[j]) { c->err = w.list[j]->err; return rcs[j]; }
+    for (size_t j = 0; j < k; j++)
+        if (rcs[j]) { std::lock_guard<std::mutex> lk(c->mu); c->err = w.list[j]->err; return rcs[j]; }
     return 0;
 }
 

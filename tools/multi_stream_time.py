@@ -27,8 +27,10 @@ def rate(fn, reps=3):
     return S / 1e6 / ((time.perf_counter() - t0) / reps)
 
 
-for label, ctx in (("one", mz.Context(devs[0])), ("many", mz.Context(devices=devs))):
-    for pinned in (True, False):
+variants = (("one", mz.Context(devs[0])), ("many", mz.Context(devices=devs)))
+# (every variant twice, interleaved: the first thing measured on a fresh box runs on cold clocks and cold page-locked buffers)
+for label, ctx in variants + variants:
+    for pinned in (True,):
         mk = (lambda n: torch.empty(n, dtype=torch.uint8, pin_memory=True)) if pinned else (lambda n: torch.empty(n, dtype=torch.uint8))
         psrc = mk(S); psrc.numpy()[:] = host
         cap = L.mlz_stream_bound(S, BLOCK, 0)
@@ -42,4 +44,3 @@ for label, ctx in (("one", mz.Context(devs[0])), ("many", mz.Context(devices=dev
             res[nm] = rate(lambda: L.mlz_stream_decode(ctx.handle, flags, pst.data_ptr(), n, pdec.data_ptr(), S))
         assert bytes(pdec.numpy()) == host.tobytes()
         print(label, "pinned" if pinned else "pageable", {k: round(v) for k, v in res.items()}, flush=True)
-    ctx.close()

@@ -140,6 +140,8 @@ struct mlz_ctx {
     int l2_free = 1;           // option 14 (default on): LevelBalanced without the tile-level constraint (better ratio; its blocks decode through the general path)
     uint64_t gen_fallbacks = 0;  // decode calls whose general blocks took the tile chain because the general pass's buffers could not be allocated (mlz_get_counter 5)
     int gen_force_packed = 0;  // tests: every tile of a general block takes the byte-packed pool (the fallback path)
+    int level0_by_e = 1;       // option 23: few level-0 tiles are decoded by dec_level0_kernel before the exec pass (0: by the exec pass, rounds 2-5)
+    bool l0_attr = false;
     int fuse_ser = 1;          // option 21: the match kernel serializes its pieces itself (0: serialize_pieces_kernel, rounds 2-5; cross-checks)
     // host-pointer staging
     DevBuf d_in, d_out, d_len, d_crc, d_crc_tabs, d_crc_tiles;
@@ -594,9 +596,20 @@ int decode_parallel(mlz_ctx* c, hipStream_t st, const uint8_t* d_src, uint8_t* d
     {
         Timer t(c, T_DEC_EXEC, st);
         unsigned long long* prof = c->prof_on ? c->d_prof.as<unsigned long long>() : nullptr;
+        // level-0 tiles first, by role E of the general pass, when they are few (dec_level0_kernel; option 23 = 0: off)
+        uint32_t l0_grid = 0;
+        if (tiles && c->level0_by_e && !c->index_passes && c->decode_algo == 0) {
+            if (!c->l0_attr) {
+                HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(dec_level0_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kGenLds));
+                c->l0_attr = true;
+            }
+            l0_grid = std::min<uint32_t>(uint32_t(c->n_cus), tiles);
+            hipLaunchKernelGGL(dec_level0_kernel, dim3(l0_grid), dim3(kGenThreads), kGenLds, st, d_src, d_dst, blocks, dec, tok_pos, round_d, round_rep, tile_start,
+                               order, tile_block, tile_done, gen);
+        }
         if (tiles)
             hipLaunchKernelGGL(dec_exec2_kernel, dim3(tiles), dim3(kExecThreads), kExecLds, st, d_src, d_dst, blocks, tile_block, dec, tile_start, tok_pos,
-                               round_d, round_rep, order, tile_done, ticket, tiles, prof);
+                               round_d, round_rep, order, tile_done, ticket, tiles, prof, reinterpret_cast<const uint32_t*>(gen), l0_grid);
     }
     {
         Timer tg(c, T_DEC_GENERAL, st);   // (+ the result pass)
@@ -1107,6 +1120,7 @@ int mlz_set_option(mlz_ctx* c, int opt, int64_t value) {
     case MLZ_OPT_DEVICE_GROUP: c->device_group = size_t(value > 0 ? value : 1) << 20; return 0;  // MiB of uncompressed data per internal group of a device batch
     case 18: c->far_slices_l2 = int(value); return 0;  // debug / cross-check: LevelBalanced's far tables by the slice kernel of round 4
     case MLZ_OPT_L2_GAP: if (value < 1 || value > 16) return -MLZ_ERR_ARG; c->l2_gap = int(value); return 0;
+    case 23: c->level0_by_e = int(value); return 0;  // decode: 1 (default) = level-0 tiles, when no more than CUs, by dec_level0_kernel before the exec pass; 0 = by the exec pass
     case 21: c->fuse_ser = int(value); return 0;  // encode: 1 (default) = the match kernel serializes its pieces itself, 0 = the separate serializer kernel of rounds 2-5 (cross-checks)
     case 20: c->gen_settle_cap = int(value); return 0;  // tuning: role S workgroups of the general pass at most
     case 14: c->l2_free = int(value); return 0;  // LevelBalanced: 1 = no tile levels (ratio of the reference's L2 and better; blocks decode as general blocks)

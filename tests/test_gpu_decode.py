@@ -481,3 +481,35 @@ def test_token_stream_longer_than_its_output(ctx):
     assert O.decode_body(bad, n)[0] != 0
     assert mz.decode_block(bad, n, ctx)[0] == 1
     assert mz.decode_block(bytes(9 << 20), 100, ctx)[0] == 1
+
+
+def test_level0_tiles_by_the_parallel_kernel_or_by_the_exec_pass(ctx):
+    # Round 6: when a batch has no more level-0 tiles than the device has CUs, dec_level0_kernel decodes them (role E of the general pass: pointer jumping
+    # in LDS, no ordered chain) before the exec pass; option 23 = 0 leaves them to the exec pass as in rounds 2-5.  Same bytes, same verdicts:
+    # own streams of every level pattern and block class, damaged own streams (the damage lands in level-0 tiles as well), the reference's negative corpus.
+    import zipfile, os
+    other = mz.Context(0)
+    other.set_option(23, 0)
+    try:
+        rng = np.random.default_rng(17)
+        blocks, want = [], []
+        for i, n in enumerate([8 << 20, (3 << 20) + 77, 700_001, 65_536 + 9, 32_768, 40_000, 33, 1 << 20]):
+            d = (synth.enwik_like if i & 1 else synth.json_like)(n, seed=70 + i)
+            for lv in (mz.LevelSuperFast, mz.LevelFastest):
+                blocks.append(mz.Encode(d, lv, ctx)); want.append(d.tobytes())
+        assert mz.decode_batch(blocks, ctx) == want and mz.decode_batch(blocks, other) == want
+        # damage: a flipped byte every 32 KiB of stream or so, one variant per block
+        for k, b in enumerate(blocks[:8]):
+            bad = bytearray(b)
+            for pos in range(7 + 131 * k, len(bad), max(1000, len(bad) // 9)):
+                bad[pos] ^= int(rng.integers(1, 256))
+            r = [gpu_decode_result(bytes(bad), c) for c in (ctx, other)]
+            assert r[0] == r[1] == oracle_decode_result(bytes(bad)), k
+        n = 0
+        for name in ("block-corpus-dec.zip", "dec-block-regressions.zip"):
+            for label, blob in load_zip(name):
+                assert gpu_decode_result(blob, other) == gpu_decode_result(blob, ctx), label
+                n += 1
+        assert n > 500
+    finally:
+        other.close()

@@ -30,13 +30,15 @@ ctx.set_option(7, buf.ctypes.data)
 t = buf.reshape(-1, 4)
 ntiles = sum((l + (32 << 10) - 1) // (32 << 10) for l in blk_len)
 t = t[:ntiles]
-lvl = (t[:, 3] >> np.uint64(60)).astype(int)
+valid = t[:, 3] != 0
+lvl = np.where(valid, (t[:, 3] >> np.uint64(60)).astype(int), -1)   # (-1: not traced — level-0 tiles decoded by dec_level0_kernel)
+n_alone = (t[:, 2] >> np.uint64(52)).astype(int); n_pass = ((t[:, 2] >> np.uint64(40)) & np.uint64(0xfff)).astype(int) * 4
 tt = t.copy(); tt[:, 3] &= np.uint64((1 << 60) - 1)
 hwid = (tt[:, 0] >> np.uint64(40)).astype(np.int64); tt &= np.uint64((1 << 40) - 1)   # (the clock itself has more than 40 bits after some days of uptime: every column is cut the same way)
 nchunks = (t[:, 1] >> np.uint64(48)).astype(int)
-t0 = tt[:, 0].min()
+t0 = tt[valid, 0].min()
 us = (tt - t0).astype(np.float64) / 100.0  # 100 MHz -> microseconds
-print("tiles", ntiles, "span %.0f us" % us[:, 3].max())
+print("tiles", ntiles, "traced", int(valid.sum()), "span %.0f us" % us[valid, 3].max())
 for L in range(4):
     m = lvl == L
     if not m.any(): continue
@@ -55,14 +57,22 @@ for L in range(4):
     print("level %d: rounds per tile %d..%d (median %d); corr(loop time, rounds) = %.2f; loop = %.2f us/round * rounds + %.0f us; residual std %.1f us" % (
         L, nc.min(), nc.max(), np.median(nc), r, fit[0], fit[1], np.std(loop - np.polyval(fit, nc))))
 
-# placement: tiles of level 0 per CU and how their loop time depends on it
+# level-1 tiles: what the slow ones have in common — position in the block (tile index mod 16), rounds, the CU they ran on
+tile_idx = np.concatenate([np.arange((l + (32 << 10) - 1) // (32 << 10)) for l in blk_len])
 xcc = hwid & 0xf; hw = hwid >> 4
 cu = (hw >> 8) & 0xf; sh = (hw >> 12) & 1; se = (hw >> 13) & 7
 cuid = xcc * 1000 + se * 100 + sh * 50 + cu
-m0 = lvl == 0
-ids, inv, cnt = np.unique(cuid[m0], return_inverse=True, return_counts=True)
-print("distinct CUs seen by level-0 tiles:", ids.size, " tiles per CU histogram:", np.bincount(cnt))
-loop0 = (us[m0, 2] - us[m0, 1])
-for k in sorted(set(cnt)):
-    sel = cnt[inv] == k
-    print("  level-0 tiles on CUs holding %d of them: n=%d loop median %.0f max %.0f" % (k, sel.sum(), np.median(loop0[sel]), loop0[sel].max()))
+for L in (1, 2):
+    m = lvl == L
+    loop = us[m, 2] - us[m, 1]
+    print("level %d loop time by tile index mod 16:" % L, {int(k): "%.0f" % np.median(loop[tile_idx[m] % 16 == k]) for k in sorted(set(tile_idx[m] % 16))})
+    q = np.argsort(loop)
+    lo, hi = q[:len(q) // 10], q[-(len(q) // 10):]
+    print("  fastest tenth: loop %.0f, rounds %.1f, copies alone %.0f, passes %.0f;  slowest tenth: loop %.0f, rounds %.1f, copies alone %.0f, passes %.0f;  corr(loop, alone) %.2f corr(loop, passes) %.2f" % (
+        loop[lo].mean(), nchunks[m][lo].mean(), n_alone[m][lo].mean(), n_pass[m][lo].mean(), loop[hi].mean(), nchunks[m][hi].mean(), n_alone[m][hi].mean(), n_pass[m][hi].mean(),
+        np.corrcoef(loop, n_alone[m])[0, 1], np.corrcoef(loop, n_pass[m])[0, 1]))
+    ids, inv, cnt = np.unique(cuid[m], return_inverse=True, return_counts=True)
+    per_cu = np.array([loop[inv == i].mean() for i in range(ids.size)])
+    print("  %d distinct (xcc, se, sh, cu) ids; mean loop per id: min %.0f median %.0f max %.0f; tiles per id %d..%d" % (ids.size, per_cu.min(), np.median(per_cu), per_cu.max(), cnt.min(), cnt.max()))
+    byx = {int(x): "%.0f" % np.median(loop[(xcc[m] == x)]) for x in sorted(set(xcc[m]))}
+    print("  median loop by XCC:", byx)

@@ -29,7 +29,8 @@ mlz_decode_batch -> pinned host memory, PCIe included; never the headline value)
 configs at one-GPU scale: config3_json_L2 (JSON stream, LevelBalanced, ratio against the oracle's L2), config4_incompressible_1GiB
 (every block stored), config5_L3_64KiB_decode (4096 x 64 KiB blocks made by the oracle's LevelSmallest on the CPU), small_stream_blocks
 (4 KiB and 16 KiB blocks), each with its kernel times; config3_json_L2_4GiB (config 3 at its stated size on one GPU: block legs, one
-framed stream written and read, workspace held) and crc (the device CRC pass).
+framed stream written and read, workspace held) and crc (the device CRC pass).  With N > 1 rank 0 also runs `--single-process` over the N devices as a
+child process while the other ranks wait (config.single_process_all_devices: the host-to-host rates of one process over the node).
 """
 import argparse
 import ctypes as C
@@ -636,6 +637,32 @@ def main():
         except Exception as ex:      # the headline stays valid without it; every rank fails alike (same sizes, same calls) or the barrier would hang
             strong = {"failed": "%s: %s" % (type(ex).__name__, str(ex)[:300])}
 
+    # ---- N > 1: the same node through ONE process (mlz_init_devices over all N devices, host-pointer calls, pinned memory): the form a Go host binds.
+    # Rank 0 starts `bench.py --gpus N --single-process` as a CHILD process and the other ranks wait at the barrier below (their GPUs are idle: the timed
+    # legs are over).  A child, because that path has never run on more than one GPU: whatever it does on a real node, the line above it survives.
+    # PCIe-inclusive, never `value`. ----
+    single_process = None
+    if dist is not None and world > 1 and args.level == 1 and not args.file:
+        if rank == 0:
+            try:
+                env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "GROUP_RANK", "ROLE_RANK",
+                                                                        "LOCAL_WORLD_SIZE", "ROLE_WORLD_SIZE", "TORCHELASTIC_RUN_ID", "MINLZ_BENCH_FORCE_DIST")}
+                pr = subprocess.run([sys.executable, os.path.abspath(__file__), "--gpus", str(world), "--single-process", "--steps", "12", "--bytes", str(S),
+                                     "--workload", args.workload], env=env, capture_output=True, text=True, timeout=600)
+                lines = [l for l in pr.stdout.splitlines() if l.startswith("{")]
+                if pr.returncode == 0 and lines:
+                    cj = json.loads(lines[-1])
+                    single_process = {"value_MBps": cj["value"], "what": cj["metric"], "end_to_end_MBps": cj["config"]["end_to_end_MBps"],
+                                      "one_device_same_input_MBps": cj["config"]["one_device_same_input_MBps"], "devices": cj["config"]["devices"],
+                                      "speedup_pair": cj["config"]["speedup_pair"], "speedup_stream_pair": cj["config"]["speedup_stream_pair"]}
+                    if "TEST_MODE" in cj["config"]:
+                        single_process["TEST_MODE"] = cj["config"]["TEST_MODE"]
+                else:
+                    single_process = {"failed": "exit code %d: %s" % (pr.returncode, (pr.stderr or "")[-300:])}
+            except Exception as ex:  # noqa: BLE001  (the headline stays valid without it)
+                single_process = {"failed": "%s: %s" % (type(ex).__name__, str(ex)[:300])}
+        dist.barrier()
+
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
@@ -942,6 +969,8 @@ def main():
         cfg["gather"] = gather_info
     if strong is not None:
         cfg["config3_strong"] = strong
+    if single_process is not None:
+        cfg["single_process_all_devices"] = single_process
     out = {
         "metric": "MB/s encode+decode, 8MB blocks %s" % {1: "L1", 2: "L2 (LevelBalanced)", -1: "L0 (LevelSuperFast)", 0: "uncompressed"}.get(args.level, "level %d" % args.level),
         "value": round(value, 1),

@@ -220,3 +220,7 @@ def test_bench_two_ranks_on_one_gpu(mode):
         cs = d["config"]["config3_strong"]
         assert "failed" not in cs, cs
         assert cs["ranks"] == 2 and len(cs["kernel_ms_per_rank"]) == 2 and len(cs["rank_ms_before_barrier"]) == 2 and cs["reader"]["decode_MBps"] > 0
+        # round 6: rank 0 also runs the node through ONE process (mlz_init_devices) as a child, the other rank waiting at a barrier
+        sp = d["config"]["single_process_all_devices"]
+        assert "failed" not in sp, sp
+        assert sp["devices"] == [0, 0] and sp["end_to_end_MBps"]["pair"] > 0 and sp["end_to_end_MBps"]["stream_pair"] > 0 and "TEST_MODE" in sp

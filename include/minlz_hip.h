@@ -194,6 +194,7 @@ int64_t mlz_stream_encode_gather_device(mlz_ctx* ctx, int level, uint32_t block_
 #define MLZ_OPT_FUSED_SERIALIZER 21 /* encode: 1 (default) = the match kernel's waves turn their own token records into token bytes (tile bytes and ring in LDS, records and
                                 * far-source lines still in the L2); 0 = the separate serializer kernel of rounds 2-5 on the same records (byte-identical; cross-checks) */
 #define MLZ_OPT_LEVEL0_KERNEL 23 /* decode: 1 (default) = a batch's level-0 tiles, when no more than the device has CUs, are decoded by dec_level0_kernel before the exec pass; 0 = by the exec pass (cross-checks) */
+#define MLZ_OPT_FOLD_LAYOUT 24  /* encode: 1 (default) = a group whose every block has tiles and room gets its layout (piece offsets, stored-or-not, header, length) from the gather kernel; 0 = always encode_layout_kernel (cross-checks) */
 #define MLZ_OPT_INDEX_PASSES 15 /* decode, cross-checks: 1 = the index pass as the three kernels of rounds 2-3 instead of dec_index1 / dec_index2 / dec_viol (default 0) */
 /* (debug, timing experiments: option 16 = 1 makes mlz_decode_batch_device return after the index pass, without output) */
 #define MLZ_OPT_GEN_SPIN 9     /* patience of the general-block decode with a tile's ready flag, in polls (~0.3 us each; default 2^24); tests */

@@ -140,6 +140,7 @@ struct mlz_ctx {
     int l2_free = 1;           // option 14 (default on): LevelBalanced without the tile-level constraint (better ratio; its blocks decode through the general path)
     uint64_t gen_fallbacks = 0;  // decode calls whose general blocks took the tile chain because the general pass's buffers could not be allocated (mlz_get_counter 5)
     int gen_force_packed = 0;  // tests: every tile of a general block takes the byte-packed pool (the fallback path)
+    int fold_layout = 1;       // option 24: the encode layout rides in the gather kernel when every block of the group has tiles and room (0: always encode_layout_kernel)
     int level0_by_e = 1;       // option 23: few level-0 tiles are decoded by dec_level0_kernel before the exec pass (0: by the exec pass, rounds 2-5)
     bool l0_attr = false;
     int fuse_ser = 1;          // option 21: the match kernel serializes its pieces itself (0: serialize_pieces_kernel, rounds 2-5; cross-checks)
@@ -442,15 +443,26 @@ int encode_device_group(mlz_ctx* c, hipStream_t st, int level, const uint8_t* d_
             }
         }
     }
-    {
+    // The layout (piece offsets, stored-or-not, header, length) rides in the gather when every block of the group has tiles and room — the common case;
+    // an empty, oversize or too tightly bounded block needs encode_layout_kernel's verdicts (option 24 = 0: always the separate kernel).
+    bool fold = c->fold_layout && tiles > 0 && level != MLZ_LEVEL_UNCOMPRESSED;
+    for (int i = 0; fold && i < n; i++) {
+        const uint64_t len = desc[i].src_len;
+        if (len == 0 || len > kMaxBlockSize || desc[i].dst_cap < (with_header ? len + 2 : len)) fold = false;
+    }
+    if (!fold) {
         Timer t(c, T_ENC_LAYOUT, st);
         hipLaunchKernelGGL(encode_layout_kernel, dim3(n), dim3(64), 0, st, blocks, c->d_tile_size.as<uint32_t>(), c->d_tile_out.as<uint32_t>(), d_dst,
                            d_out_len, c->d_flags.as<uint32_t>(), level, with_header ? 1 : 0, sub_log);
     }
     if (tiles > 0) {
         Timer t(c, T_ENC_GATHER, st);
-        hipLaunchKernelGGL(encode_gather2_kernel, dim3(tiles), dim3(256), 0, st, d_src, blocks, tile_block, c->d_scratch.as<uint8_t>(),
-                           c->d_tile_size.as<uint32_t>(), c->d_tile_out.as<uint32_t>(), d_dst, c->d_flags.as<uint32_t>(), with_header ? 1 : 0);
+        if (fold)
+            hipLaunchKernelGGL(encode_gather2_kernel<true>, dim3(tiles), dim3(256), 0, st, d_src, blocks, tile_block, c->d_scratch.as<uint8_t>(),
+                               c->d_tile_size.as<uint32_t>(), c->d_tile_out.as<uint32_t>(), d_dst, c->d_flags.as<uint32_t>(), with_header ? 1 : 0, level, d_out_len);
+        else
+            hipLaunchKernelGGL(encode_gather2_kernel<false>, dim3(tiles), dim3(256), 0, st, d_src, blocks, tile_block, c->d_scratch.as<uint8_t>(),
+                               c->d_tile_size.as<uint32_t>(), c->d_tile_out.as<uint32_t>(), d_dst, c->d_flags.as<uint32_t>(), with_header ? 1 : 0, level, d_out_len);
     }
     HIPCHK(c, hipGetLastError());
     return 0;
@@ -1120,6 +1132,7 @@ int mlz_set_option(mlz_ctx* c, int opt, int64_t value) {
     case MLZ_OPT_DEVICE_GROUP: c->device_group = size_t(value > 0 ? value : 1) << 20; return 0;  // MiB of uncompressed data per internal group of a device batch
     case 18: c->far_slices_l2 = int(value); return 0;  // debug / cross-check: LevelBalanced's far tables by the slice kernel of round 4
     case MLZ_OPT_L2_GAP: if (value < 1 || value > 16) return -MLZ_ERR_ARG; c->l2_gap = int(value); return 0;
+    case 24: c->fold_layout = int(value); return 0;  // encode: 1 (default) = layout inside the gather kernel where possible, 0 = always the separate layout kernel (cross-checks)
     case 23: c->level0_by_e = int(value); return 0;  // decode: 1 (default) = level-0 tiles, when no more than CUs, by dec_level0_kernel before the exec pass; 0 = by the exec pass
     case 21: c->fuse_ser = int(value); return 0;  // encode: 1 (default) = the match kernel serializes its pieces itself, 0 = the separate serializer kernel of rounds 2-5 (cross-checks)
     case 20: c->gen_settle_cap = int(value); return 0;  // tuning: role S workgroups of the general pass at most

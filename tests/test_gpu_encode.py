@@ -512,3 +512,27 @@ def test_fused_serializer_writes_the_same_bytes(level):
             assert O.decode(blk, guard=64) == p.tobytes()
     finally:
         a.close(); b_.close()
+
+
+@pytest.mark.parametrize("level", [-1, 1, 2])
+def test_layout_inside_the_gather_kernel_writes_the_same_blocks(level):
+    # Round 6: a group whose every block has tiles and room gets its layout (piece offsets, stored-or-not, header, length) from the gather kernel itself;
+    # option 24 = 0 always runs encode_layout_kernel.  Same blocks, same lengths — compressible, stored (random), tiny, ragged, one-tile and 8 MiB blocks,
+    # through Encode (header) and encode_block (tokens only: 0 = incompressible).
+    parts = [synth.enwik_like(8 << 20, 3), synth.random_bytes(1 << 20, seed=2), synth.text_like(15, 7), synth.text_like(16, 7), synth.json_like((3 << 20) + 77, 4),
+             synth.text_like(32_768, 5), synth.text_like(32_769, 6), synth.pattern("zeros", 2_000_001), synth.text_like(5, 11), synth.random_bytes(40_000, seed=3)]
+    a, b_ = mz.Context(0), mz.Context(0)
+    try:
+        b_.set_option(24, 0)
+        raw = [p.tobytes() for p in parts]
+        fa, fb = mz.encode_batch(raw, level, a), mz.encode_batch(raw, level, b_)
+        assert fa == fb
+        for blk, p in zip(fa, raw):
+            assert O.decode(blk, guard=64) == p
+        for p in raw:
+            assert mz.encode_block(p, level, a) == mz.encode_block(p, level, b_)
+        # a group with an empty block falls back to the separate kernel and still gives the same bytes
+        mixed = raw[:3] + [b""] + raw[3:5]
+        assert mz.encode_batch(mixed, level, a) == mz.encode_batch(mixed, level, b_)
+    finally:
+        a.close(); b_.close()
